@@ -1,0 +1,327 @@
+// channelize.hip -- stage 1 of the hot path on gfx950: sample conversion x window, sliding FFT, bin
+// pick + magnitude.  Replaces rtl_airband.cpp:424-511 (and the NEON samplefft(), rtl_airband_neon.s:28-83,
+// and FFTW3f / hello_fft) for a whole tile of consecutive windows per workgroup.
+//
+// One workgroup = TW consecutive windows of one stream.  The byte span the TW windows cover
+// ((TW-1)*hop + fft_size samples; windows overlap 3.2x at fft 512) is read from HBM ONCE with 16-byte
+// coalesced loads into LDS; every window then converts its samples out of LDS.  An FFT of N points is
+// done by N/8 lanes, 8 points per lane, as radix-2 DIT stages taken three at a time in registers with
+// one LDS exchange between passes.  The arithmetic of every butterfly is the documented FFT spec
+// (DESIGN.md): t = w*b as {fma(-b.im, w.im, b.re*w.re), fma(b.im, w.re, b.re*w.im)}, a' = a + t,
+// b' = a - t, so the result is bit-identical to the CPU oracle (zero signs aside).  Only the
+// channel bins leave the chip: magnitude (and re/im for channels that need raw I/Q), staged per tile
+// in LDS and written as contiguous rows of the [stream][channel][time] planes stage 2 reads.
+//
+// Compile with -ffp-contract=off: products and sums must round separately except where fma is spelled.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace mi {
+namespace {
+
+template <int L>
+struct FftGeom {
+    static constexpr int N = 1 << L;
+    static constexpr int TPF = N / 8;                      // lanes per FFT
+    static constexpr int BLOCK = TPF < 256 ? 256 : TPF;    // threads per workgroup
+    static constexpr int F = BLOCK / TPF;                  // FFTs in flight per workgroup
+    static constexpr int NPASS = (L + 2) / 3;
+    static constexpr int TW = L <= 10 ? 64 : (L == 11 ? 32 : (L == 12 ? 16 : 8));  // windows per tile
+    static constexpr int XN = N + N / 8;                   // padded exchange length (float2)
+};
+
+__device__ __forceinline__ int xpad(int p) {
+    return p + (p >> 3);
+}
+
+// generic butterfly (a, b) -> (a + w b, a - w b)
+__device__ __forceinline__ void bfly(float2& a, float2& b, const float2 w) {
+    const float tr = __builtin_fmaf(-b.y, w.y, b.x * w.x);
+    const float ti = __builtin_fmaf(b.y, w.x, b.x * w.y);
+    const float2 a0 = a;
+    a.x = a0.x + tr;
+    a.y = a0.y + ti;
+    b.x = a0.x - tr;
+    b.y = a0.y - ti;
+}
+// w = 1
+__device__ __forceinline__ void bfly_one(float2& a, float2& b) {
+    const float2 a0 = a, b0 = b;
+    a.x = a0.x + b0.x;
+    a.y = a0.y + b0.y;
+    b.x = a0.x - b0.x;
+    b.y = a0.y - b0.y;
+}
+// w = -j : t = (b.im, -b.re)
+__device__ __forceinline__ void bfly_negj(float2& a, float2& b) {
+    const float2 a0 = a, b0 = b;
+    a.x = a0.x + b0.y;
+    a.y = a0.y - b0.x;
+    b.x = a0.x - b0.y;
+    b.y = a0.y + b0.x;
+}
+
+// Pass K covers DIT stages 3K+1 .. min(3K+3, L).  A lane owns 8 elements that are closed under those
+// stages: groups of G = 2^nst elements at stride S = 8^K.
+template <int L, int K>
+struct Pass {
+    static constexpr int S = 1 << (3 * K);
+    static constexpr int NST = (L - 3 * K) >= 3 ? 3 : (L - 3 * K);
+    static constexpr int G = 1 << NST;
+    static constexpr int GROUPS = 8 / G;
+    static constexpr int NTW = GROUPS * (G - 1);  // distinct twiddles a lane needs in this pass (<= 7)
+
+    __device__ static __forceinline__ int pos(int tau, int gi, int ri) {
+        const int u = tau * GROUPS + gi;
+        const int hi = u >> (3 * K);
+        const int lo = u & (S - 1);
+        return ((hi * G + ri) << (3 * K)) + lo;
+    }
+    // twiddle exponent of the butterfly (ri, ri + 2^a), stage 3K+1+a
+    __device__ static __forceinline__ int tw_exp(int tau, int gi, int a, int m) {
+        const int u = tau * GROUPS + gi;
+        const int lo = u & (S - 1);
+        return (m * S + lo) * ((1 << L) >> (3 * K + 1 + a));
+    }
+    __device__ static __forceinline__ void load_tw(int tau, const float2* __restrict__ tw, float2 (&r)[7]) {
+#pragma unroll
+        for (int gi = 0; gi < GROUPS; ++gi)
+#pragma unroll
+            for (int a = 0; a < NST; ++a)
+#pragma unroll
+                for (int m = 0; m < (1 << a); ++m)
+                    r[gi * (G - 1) + ((1 << a) - 1) + m] = tw[tw_exp(tau, gi, a, m)];
+    }
+    __device__ static __forceinline__ void run(float2 (&x)[8], const float2 (&r)[7]) {
+#pragma unroll
+        for (int gi = 0; gi < GROUPS; ++gi)
+#pragma unroll
+            for (int a = 0; a < NST; ++a)
+#pragma unroll
+                for (int ri = 0; ri < G; ++ri)
+                    if ((ri & (1 << a)) == 0) {
+                        const int m = ri & ((1 << a) - 1);
+                        bfly(x[gi * G + ri], x[gi * G + ri + (1 << a)], r[gi * (G - 1) + ((1 << a) - 1) + m]);
+                    }
+    }
+};
+
+// pass 0: S = 1, lo = 0, twiddles are 1, -j, W8 = tw[N/8], W8^3 = tw[3N/8]
+__device__ __forceinline__ void pass0(float2 (&x)[8], const float2 w8, const float2 w83) {
+    bfly_one(x[0], x[1]);
+    bfly_one(x[2], x[3]);
+    bfly_one(x[4], x[5]);
+    bfly_one(x[6], x[7]);
+    bfly_one(x[0], x[2]);
+    bfly_negj(x[1], x[3]);
+    bfly_one(x[4], x[6]);
+    bfly_negj(x[5], x[7]);
+    bfly_one(x[0], x[4]);
+    bfly(x[1], x[5], w8);
+    bfly_negj(x[2], x[6]);
+    bfly(x[3], x[7], w83);
+}
+
+template <int L, int K>
+__device__ __forceinline__ void later_passes(float2 (&x)[8], const float2 (&twr)[FftGeom<L>::NPASS][7], float2* __restrict__ xch, int tau) {
+    if constexpr (K < FftGeom<L>::NPASS) {
+        using P = Pass<L, K>;
+#pragma unroll
+        for (int gi = 0; gi < P::GROUPS; ++gi)
+#pragma unroll
+            for (int ri = 0; ri < P::G; ++ri)
+                x[gi * P::G + ri] = xch[xpad(P::pos(tau, gi, ri))];
+        P::run(x, twr[K]);
+#pragma unroll
+        for (int gi = 0; gi < P::GROUPS; ++gi)
+#pragma unroll
+            for (int ri = 0; ri < P::G; ++ri)
+                xch[xpad(P::pos(tau, gi, ri))] = x[gi * P::G + ri];
+        __syncthreads();
+        later_passes<L, K + 1>(x, twr, xch, tau);
+    }
+}
+
+template <int L, int K>
+__device__ __forceinline__ void load_all_tw(int tau, const float2* __restrict__ tw, float2 (&twr)[FftGeom<L>::NPASS][7]) {
+    if constexpr (K < FftGeom<L>::NPASS) {
+        Pass<L, K>::load_tw(tau, tw, twr[K]);
+        load_all_tw<L, K + 1>(tau, tw, twr);
+    }
+}
+
+template <int SFMT>
+__device__ __forceinline__ float2 fetch_sample(const unsigned char* __restrict__ span, int byte_off, const float* __restrict__ lut, float scale,
+                                               float w) {
+    float2 v;
+    if constexpr (SFMT == MI_SFMT_U8 || SFMT == MI_SFMT_S8) {
+        const unsigned short b = *reinterpret_cast<const unsigned short*>(span + byte_off);
+        v.x = lut[b & 0xff] * w;  // rtl_airband.cpp:473-474
+        v.y = lut[b >> 8] * w;
+    } else if constexpr (SFMT == MI_SFMT_S16) {
+        const short2 s = *reinterpret_cast<const short2*>(span + byte_off);
+        v.x = scale * static_cast<float>(s.x) * w;  // rtl_airband.cpp:438-439
+        v.y = scale * static_cast<float>(s.y) * w;
+    } else {
+        const float2 s = *reinterpret_cast<const float2*>(span + byte_off);
+        v.x = scale * s.x * w;  // rtl_airband.cpp:456-457
+        v.y = scale * s.y * w;
+    }
+    return v;
+}
+
+template <int L, int SFMT>
+__global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const ChannelizeArgs a) {
+    using Gm = FftGeom<L>;
+    constexpr int N = Gm::N, TPF = Gm::TPF, F = Gm::F, TW = Gm::TW, XN = Gm::XN, BLOCK = Gm::BLOCK;
+    constexpr int BPS2 = (SFMT == MI_SFMT_S16 ? 4 : (SFMT == MI_SFMT_F32 ? 8 : 2));  // bytes per complex sample
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int stream = blockIdx.y;
+    const unsigned w0 = blockIdx.x * TW;
+    const int nw = min(static_cast<unsigned>(TW), a.nfft - w0);
+
+    const unsigned span_alloc = (static_cast<unsigned>(TW - 1) * a.hop_bytes + N * BPS2 + 16 + 15) & ~15u;
+    unsigned char* span = lds;
+    float* lut = reinterpret_cast<float*>(lds + span_alloc);
+    float2* xch_all = reinterpret_cast<float2*>(lds + span_alloc + 1024);
+    float* out_mag = reinterpret_cast<float*>(xch_all + F * XN);
+    float2* out_iq = reinterpret_cast<float2*>(out_mag + a.nch * TW);
+
+    // ---- HBM -> LDS: the byte span of this tile, each byte read once, 16 B per lane ----
+    const unsigned char* gbase = a.iq + static_cast<size_t>(stream) * a.stream_stride;
+    const long long b0 = static_cast<long long>(w0) * a.hop_bytes;
+    const unsigned mis = static_cast<unsigned>(reinterpret_cast<uintptr_t>(gbase + b0) & 15);
+    const unsigned need = static_cast<unsigned>(nw - 1) * a.hop_bytes + N * BPS2;
+    const unsigned nchunks = (mis + need + 15) >> 4;
+    for (unsigned c = tid; c < nchunks; c += BLOCK) {
+        const long long off = b0 - mis + 16ll * c;
+        uint4 v;
+        if (off >= 0 && off + 16 <= static_cast<long long>(a.valid_bytes)) {
+            v = *reinterpret_cast<const uint4*>(gbase + off);
+        } else {
+            unsigned char tmp[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long long o = off + i;
+                tmp[i] = (o >= 0 && o < static_cast<long long>(a.valid_bytes)) ? gbase[o] : 0;
+            }
+            v = *reinterpret_cast<uint4*>(tmp);
+        }
+        *reinterpret_cast<uint4*>(span + 16 * c) = v;
+    }
+    if constexpr (SFMT == MI_SFMT_U8 || SFMT == MI_SFMT_S8) {
+        for (int i = tid; i < 256; i += BLOCK)
+            lut[i] = a.levels[i];
+    }
+
+    // ---- per-lane constants: window coefficients of the 8 samples this lane converts, twiddles ----
+    const int f = tid / TPF;
+    const int tau = tid - f * TPF;
+    float2* xch = xch_all + f * XN;
+    const int nrev = (L > 3) ? static_cast<int>(__brev(static_cast<unsigned>(tau)) >> (32 - (L - 3))) : 0;
+    int nidx[8];
+    float wreg[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int rev3 = ((r & 1) << 2) | (r & 2) | ((r >> 2) & 1);
+        nidx[r] = rev3 * TPF + nrev;  // natural sample index = bitrev_L(8 tau + r)
+        wreg[r] = a.window[nidx[r]];
+    }
+    const float2* tw = reinterpret_cast<const float2*>(a.tw);
+    const float2 w8 = tw[N / 8], w83 = tw[3 * N / 8];
+    float2 twr[Gm::NPASS][7];
+    load_all_tw<L, 1>(tau, tw, twr);
+    __syncthreads();
+
+    // ---- FFTs: F windows at a time ----
+    for (int it = 0; it * F < nw; ++it) {
+        const int wi = it * F + f;
+        const bool active = wi < nw;
+        float2 x[8];
+        const int wbyte = static_cast<int>(mis) + (active ? wi : 0) * static_cast<int>(a.hop_bytes);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            x[r] = fetch_sample<SFMT>(span, wbyte + nidx[r] * BPS2, lut, a.conv_scale, wreg[r]);
+        pass0(x, w8, w83);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            xch[xpad(tau * 8 + r)] = x[r];
+        __syncthreads();
+        later_passes<L, 1>(x, twr, xch, tau);
+        // natural-order spectrum now sits in xch: pick the channel bins (rtl_airband.cpp:505-511)
+        if (active) {
+            for (int c = tau; c < a.nch; c += TPF) {
+                const ChanParams& cp = a.cp[c];
+                const float2 v = xch[xpad(static_cast<int>(cp.bin))];
+                out_mag[c * TW + wi] = sqrtf(v.x * v.x + v.y * v.y);
+                if (cp.iq_row >= 0)
+                    out_iq[cp.iq_row * TW + wi] = v;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- LDS -> HBM: contiguous rows of the planes ----
+    for (int idx = tid; idx < a.nch * TW; idx += BLOCK) {
+        const int c = idx / TW, i = idx - c * TW;
+        if (i < nw)
+            a.mag[(static_cast<size_t>(stream) * a.nch + c) * a.plane_stride + a.plane_off + w0 + i] = out_mag[idx];
+    }
+    for (int idx = tid; idx < a.n_iq_rows * TW; idx += BLOCK) {
+        const int c = idx / TW, i = idx - c * TW;
+        if (i < nw)
+            a.cplx[(static_cast<size_t>(stream) * a.n_iq_rows + c) * a.plane_stride + a.plane_off + w0 + i] = out_iq[idx];
+    }
+}
+
+template <int L, int SFMT>
+hipError_t launch_one(const ChannelizeArgs& a, int nstreams, hipStream_t s) {
+    using Gm = FftGeom<L>;
+    constexpr int BPS2 = (SFMT == MI_SFMT_S16 ? 4 : (SFMT == MI_SFMT_F32 ? 8 : 2));
+    const unsigned span_alloc = (static_cast<unsigned>(Gm::TW - 1) * a.hop_bytes + Gm::N * BPS2 + 16 + 15) & ~15u;
+    const size_t lds = span_alloc + 1024 + static_cast<size_t>(Gm::F) * Gm::XN * 8 + static_cast<size_t>(a.nch) * Gm::TW * 4 +
+                       static_cast<size_t>(a.n_iq_rows) * Gm::TW * 8;
+    if (lds > 160 * 1024)
+        return hipErrorInvalidValue;
+    auto kern = k_channelize<L, SFMT>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess)
+            return e;
+    }
+    const dim3 grid((a.nfft + Gm::TW - 1) / Gm::TW, nstreams);
+    hipLaunchKernelGGL(kern, grid, dim3(Gm::BLOCK), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int L>
+hipError_t launch_fmt(const ChannelizeArgs& a, int sfmt, int nstreams, hipStream_t s) {
+    switch (sfmt) {
+        case MI_SFMT_U8: return launch_one<L, MI_SFMT_U8>(a, nstreams, s);
+        case MI_SFMT_S8: return launch_one<L, MI_SFMT_S8>(a, nstreams, s);
+        case MI_SFMT_S16: return launch_one<L, MI_SFMT_S16>(a, nstreams, s);
+        case MI_SFMT_F32: return launch_one<L, MI_SFMT_F32>(a, nstreams, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+hipError_t launch_channelize(const ChannelizeArgs& a, int log2n, int sfmt, int nstreams, hipStream_t s) {
+    if (a.nfft == 0 || nstreams == 0)
+        return hipSuccess;
+    switch (log2n) {
+        case 8: return launch_fmt<8>(a, sfmt, nstreams, s);
+        case 9: return launch_fmt<9>(a, sfmt, nstreams, s);
+        case 10: return launch_fmt<10>(a, sfmt, nstreams, s);
+        case 11: return launch_fmt<11>(a, sfmt, nstreams, s);
+        case 12: return launch_fmt<12>(a, sfmt, nstreams, s);
+        case 13: return launch_fmt<13>(a, sfmt, nstreams, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace mi

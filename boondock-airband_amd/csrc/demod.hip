@@ -1,0 +1,613 @@
+// demod.hip -- stage 2 of the hot path on gfx950: the per-channel sample loop of demodulate()
+// (rtl_airband.cpp:517-669) with Squelch (squelch.cpp), CTCSS (ctcss.cpp), NotchFilter/LowpassFilter
+// (filters.cpp), the sincos LUT derotation (util.cpp:113-127), AM AGC and the NFM discriminators
+// (rtl_airband.cpp:141-176).
+//
+// The loop is a recurrence in time (EMAs, a state machine, biquads, AGC with clip feedback): step i
+// needs the state left by step i-1.  This kernel keeps one (stream, channel) per lane with its whole
+// state in registers and walks the [stream][channel][time] planes stage 1 wrote; inputs are fetched a
+// chunk ahead so the only serial chain is arithmetic.  Few lanes are packed per wave when there are
+// few channels so that channels whose squelch states differ do not serialise each other's branches.
+//
+// Arithmetic is written operation for operation as the reference evaluates it in IEEE single precision
+// (no contraction, correctly rounded / and sqrt): squelch decisions must be bit-exact.
+// Compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace mi {
+namespace {
+
+enum : int { SQ_CLOSED = 0, SQ_OPENING = 1, SQ_CLOSING = 2, SQ_LOW_SIGNAL_ABORT = 3, SQ_OPEN = 4 };  // squelch.h:104-110
+
+constexpr int kOpenDelay = 197, kCloseDelay = 197, kLowSignalAbort = 88;  // squelch.cpp:49-51
+constexpr uint32_t kRecentSampleSize = 1000, kFlapOpensThreshold = 3;    // squelch.cpp:62-63
+
+struct Ctx {
+    ChanState s;
+    ChanParams p;  // by value: registers, not a global load per use
+    float* ring;            // Squelch::buffer_
+    const float* cc_fast;   // Goertzel coefficients
+    const float* cc_slow;
+    float* cq_fast;         // q1[kMaxTones], q2[kMaxTones]
+    float* cq_slow;
+};
+
+__device__ __forceinline__ float std_min(float a, float b) {  // std::min(a, b): b < a ? b : a
+    return (b < a) ? b : a;
+}
+
+__device__ __forceinline__ bool flapping(const Ctx& c) {  // squelch.cpp:516-518
+    return c.s.recent_open_count >= kFlapOpensThreshold;
+}
+
+__device__ __forceinline__ float squelch_level(Ctx& c) {  // squelch.cpp:164-177, cache and all
+    if (c.p.using_manual_level)
+        return c.p.manual_signal_level;
+    if (c.s.squelch_level_cache == 0.0f) {
+        if (flapping(c) && c.p.flappy_signal_ratio < c.p.normal_signal_ratio)
+            c.s.squelch_level_cache = c.p.flappy_signal_ratio * c.s.noise_floor;
+        else
+            c.s.squelch_level_cache = c.p.normal_signal_ratio * c.s.noise_floor;
+    }
+    return c.s.squelch_level_cache;
+}
+
+__device__ __forceinline__ bool has_pre(Ctx& c) {  // squelch.cpp:462-464
+    return c.s.pre_capped >= squelch_level(c);
+}
+__device__ __forceinline__ bool has_post(Ctx& c) {  // squelch.cpp:466-468
+    return c.s.using_post_filter && c.s.post_capped >= c.ring[c.s.buffer_tail];
+}
+__device__ __forceinline__ bool has_signal(Ctx& c) {  // squelch.cpp:470-475
+    if (c.s.using_post_filter)
+        return has_pre(c) && has_post(c);
+    return has_pre(c);
+}
+
+__device__ __forceinline__ void set_state(Ctx& c, int update) {  // squelch.cpp:297-361
+    const int cur = c.s.current_state;
+    if (cur == SQ_CLOSED && update == SQ_CLOSING)
+        update = SQ_CLOSED;
+    else if (cur == SQ_CLOSED && update == SQ_LOW_SIGNAL_ABORT)
+        update = SQ_CLOSED;
+    else if (cur == SQ_CLOSED && update == SQ_OPEN)
+        update = SQ_OPENING;
+    else if (cur == SQ_OPENING && update == SQ_LOW_SIGNAL_ABORT)
+        update = SQ_CLOSED;
+    else if (cur == SQ_LOW_SIGNAL_ABORT && update != SQ_LOW_SIGNAL_ABORT && update != SQ_CLOSED)
+        update = SQ_CLOSED;
+    else if (cur == SQ_OPEN && update == SQ_CLOSED)
+        update = SQ_CLOSING;
+    else if (cur == SQ_OPEN && update == SQ_OPENING)
+        update = SQ_OPEN;
+    c.s.next_state = update;
+}
+
+__device__ __forceinline__ void ctcss_reset(Ctx& c) {  // CTCSS::reset on both detectors, ctcss.cpp:165-172
+    if (!c.p.ctcss_enabled)
+        return;
+    for (int d = 0; d < c.p.ctcss_fast_ndet; ++d)
+        c.cq_fast[d] = c.cq_fast[kMaxTones + d] = 0.0f;
+    for (int d = 0; d < c.p.ctcss_slow_ndet; ++d)
+        c.cq_slow[d] = c.cq_slow[kMaxTones + d] = 0.0f;
+    c.s.cf_enough = c.s.cf_count = c.s.cf_has_tone = 0;
+    c.s.cs_enough = c.s.cs_count = c.s.cs_has_tone = 0;
+}
+
+__device__ __forceinline__ void update_current_state(Ctx& c) {  // squelch.cpp:363-460
+    ChanState& s = c.s;
+    if (s.next_state == SQ_OPENING) {
+        if (s.current_state != SQ_OPENING) {
+            s.delay = 0;
+            s.low_signal_count = 0;
+            s.using_post_filter = 0;
+            s.current_state = s.next_state;
+        } else {
+            s.delay++;
+            if (s.delay >= kOpenDelay) {
+                if (s.closed_sample_count < kRecentSampleSize) {
+                    s.recent_open_count++;
+                    if (flapping(c))
+                        s.flappy_count++;
+                    s.squelch_level_cache = 0.0f;
+                }
+                s.next_state = has_signal(c) ? SQ_OPEN : SQ_CLOSED;
+            }
+        }
+    } else if (s.next_state == SQ_CLOSING) {
+        if (s.current_state != SQ_CLOSING) {
+            s.delay = 0;
+            s.current_state = s.next_state;
+        } else {
+            s.delay++;
+            if (s.delay >= kCloseDelay) {
+                if (!has_signal(c)) {
+                    s.next_state = SQ_CLOSED;
+                } else {
+                    s.current_state = SQ_OPEN;
+                    s.next_state = SQ_OPEN;
+                }
+            }
+        }
+    } else if (s.next_state == SQ_LOW_SIGNAL_ABORT) {
+        if (s.current_state != SQ_LOW_SIGNAL_ABORT) {
+            if (s.current_state != SQ_CLOSING)
+                s.delay = 0;
+            s.current_state = s.next_state;
+        } else {
+            s.delay++;
+            if (s.delay >= kCloseDelay)
+                s.next_state = SQ_CLOSED;
+        }
+    } else if (s.next_state == SQ_OPEN && s.current_state != SQ_OPEN) {
+        s.open_count++;
+        s.current_state = s.next_state;
+    } else if (s.next_state == SQ_CLOSED && s.current_state != SQ_CLOSED) {
+        s.using_post_filter = 0;
+        s.closed_sample_count = 0;
+        s.current_state = s.next_state;
+        ctcss_reset(c);
+    } else if (s.next_state == SQ_CLOSED && s.current_state == SQ_CLOSED) {
+        if (s.closed_sample_count < kRecentSampleSize) {
+            s.closed_sample_count++;
+        } else if (s.closed_sample_count == kRecentSampleSize) {
+            s.recent_open_count = 0;
+            s.squelch_level_cache = 0.0f;
+        }
+    } else {
+        s.current_state = s.next_state;
+    }
+    s.buffer_tail = (s.buffer_tail + 1 == kSquelchRing) ? 0 : s.buffer_tail + 1;
+    s.buffer_head = (s.buffer_head + 1 == kSquelchRing) ? 0 : s.buffer_head + 1;
+}
+
+__device__ __forceinline__ void update_avg(const float cap, float& full, float& capped, const float sample) {  // squelch.cpp:501-514
+    const float decay_factor = 0.99f;
+    const float new_factor = static_cast<float>(1.0 - static_cast<double>(0.99f));
+    full = full * decay_factor + sample * new_factor;
+    if (capped >= cap && sample >= cap)
+        capped = cap;
+    else
+        capped = std_min(cap, capped * decay_factor + sample * new_factor);
+}
+
+__device__ __forceinline__ void process_raw(Ctx& c, const float sample) {  // squelch.cpp:195-246
+    ChanState& s = c.s;
+    update_current_state(c);
+    s.sample_count++;
+    if ((s.sample_count & 15u) == 0) {  // calculate_noise_floor, squelch.cpp:477-490
+        const float decay_factor = 0.97f;
+        const float new_factor = static_cast<float>(1.0 - static_cast<double>(0.97f));
+        s.noise_floor = s.noise_floor * decay_factor + std_min(s.pre_capped, s.noise_floor) * new_factor + 1e-6f;
+        s.moving_avg_cap = c.p.using_manual_level ? c.p.manual_cap : c.p.cap_factor * s.noise_floor;  // squelch.cpp:492-499
+        s.squelch_level_cache = 0.0f;
+    }
+    update_avg(s.moving_avg_cap, s.pre_full, s.pre_capped, sample);
+    if (c.p.lowpass_enabled)  // buffer_ is only ever read back through the post filter
+        c.ring[s.buffer_head] = s.pre_capped * 0.9f;
+    if (s.current_state == SQ_OPEN && !has_signal(c))
+        set_state(c, SQ_CLOSING);
+    if (s.current_state == SQ_CLOSED && has_signal(c))
+        set_state(c, SQ_OPENING);
+    if (s.current_state != SQ_CLOSED && s.current_state != SQ_LOW_SIGNAL_ABORT) {
+        if (sample >= squelch_level(c)) {
+            s.low_signal_count = 0;
+        } else {
+            s.low_signal_count++;
+            if (s.low_signal_count >= kLowSignalAbort)
+                set_state(c, SQ_LOW_SIGNAL_ABORT);
+        }
+    }
+}
+
+__device__ __forceinline__ bool should_filter(Ctx& c) {  // squelch.cpp:136-138
+    return ((has_pre(c) || c.s.current_state != SQ_CLOSED) && c.s.current_state != SQ_LOW_SIGNAL_ABORT);
+}
+
+__device__ __forceinline__ void process_filtered(Ctx& c, const float sample) {  // squelch.cpp:248-276
+    ChanState& s = c.s;
+    if (!should_filter(c))
+        return;
+    if (s.current_state == SQ_OPENING) {
+        if (s.delay < kSquelchRing)
+            return;
+        if (s.delay == kSquelchRing) {
+            s.post_full = c.ring[s.buffer_tail];
+            s.post_capped = c.ring[s.buffer_tail];
+        }
+    }
+    s.using_post_filter = 1;
+    update_avg(s.moving_avg_cap, s.post_full, s.post_capped, sample);
+    if (s.post_capped < c.ring[s.buffer_tail])
+        set_state(c, SQ_CLOSED);
+}
+
+// CTCSS::process_audio_sample on one detector set, ctcss.cpp:124-163 (+ ToneDetector, :44-55)
+__device__ __forceinline__ void ctcss_process(const float* __restrict__ coeff, float* __restrict__ q, const int ndet, const int window, int& count,
+                                              int& enough, int& has_tone, uint64_t& found, uint64_t& not_found, const float sample) {
+    for (int d = 0; d < ndet; ++d) {
+        const float q1 = q[d], q2 = q[kMaxTones + d];
+        const float q0 = coeff[d] * q1 - q2 + sample;
+        q[kMaxTones + d] = q1;
+        q[d] = q0;
+    }
+    count++;
+    if (count < window)
+        return;
+    enough = 1;
+    float total = 0.0f, maxp = 0.0f, target = 0.0f;
+    for (int d = 0; d < ndet; ++d) {
+        const float q1 = q[d], q2 = q[kMaxTones + d];
+        const float mag = q1 * q1 + q2 * q2 - q1 * q2 * coeff[d];
+        total += mag;
+        if (d == 0) {
+            target = mag;
+            maxp = mag;
+        } else if (mag > maxp) {
+            maxp = mag;
+        }
+        q[d] = 0.0f;
+        q[kMaxTones + d] = 0.0f;
+    }
+    const float avg = total / static_cast<float>(ndet);
+    if (target == maxp && target > avg) {
+        has_tone = 1;
+        found++;
+    } else {
+        has_tone = 0;
+        not_found++;
+    }
+    count = 0;
+}
+
+__device__ __forceinline__ void process_audio(Ctx& c, const float sample) {  // squelch.cpp:278-295
+    if (!c.p.ctcss_enabled)
+        return;
+    ChanState& s = c.s;
+    if (s.current_state != SQ_CLOSED) {
+        ctcss_process(c.cc_slow, c.cq_slow, c.p.ctcss_slow_ndet, c.p.ctcss_slow_window, s.cs_count, s.cs_enough, s.cs_has_tone, s.cs_found,
+                      s.cs_not_found, sample);
+        if (!s.cs_enough)
+            ctcss_process(c.cc_fast, c.cq_fast, c.p.ctcss_fast_ndet, c.p.ctcss_fast_window, s.cf_count, s.cf_enough, s.cf_has_tone, s.cf_found,
+                          s.cf_not_found, sample);
+    }
+}
+
+__device__ __forceinline__ bool is_open(const Ctx& c) {  // squelch.cpp:118-134
+    if (c.s.current_state == SQ_OPEN || c.s.current_state == SQ_CLOSING) {
+        if (c.p.ctcss_enabled)
+            return c.s.cs_enough ? (c.s.cs_has_tone != 0) : (c.s.cf_has_tone != 0);
+        return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ float fast_atan2(const float y, const float x) {  // rtl_airband.cpp:147-166
+    const float pi4 = static_cast<float>(M_PI_4), pi34 = static_cast<float>(3 * M_PI_4);
+    if (x == 0.0f && y == 0.0f)
+        return 0;
+    float yabs = y;
+    if (yabs < 0.0f)
+        yabs = -yabs;
+    float angle;
+    if (x >= 0.0f)
+        angle = pi4 - pi4 * (x - yabs) / (x + yabs);
+    else
+        angle = pi34 - pi4 * (x + yabs) / (yabs - x);
+    if (y < 0.0f)
+        return -angle;
+    return angle;
+}
+
+__global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
+    const int rows = a.nstreams * a.nch;
+    const int row = blockIdx.x * a.lanes_per_wave + threadIdx.x;
+    if (static_cast<int>(threadIdx.x) >= a.lanes_per_wave || row >= rows)
+        return;
+    const int stream = row / a.nch, ch = row - stream * a.nch;
+    Ctx c;
+    c.s = a.st[row];
+    c.p = a.cp[ch];
+    const ChanParams& P = c.p;
+    c.ring = a.sq_ring + static_cast<size_t>(row) * kSquelchRing;
+    c.cc_fast = c.cc_slow = nullptr;
+    c.cq_fast = c.cq_slow = nullptr;
+    if (P.ctcss_enabled) {
+        c.cc_fast = a.ctcss_coeff + static_cast<size_t>(P.ctcss_row) * 2 * kMaxTones;
+        c.cc_slow = c.cc_fast + kMaxTones;
+        c.cq_fast = a.ctcss_q + (static_cast<size_t>(stream) * a.n_ctcss_rows + P.ctcss_row) * 4 * kMaxTones;
+        c.cq_slow = c.cq_fast + 2 * kMaxTones;
+    }
+
+    float* __restrict__ magrow = a.mag + static_cast<size_t>(row) * a.plane_stride;
+    const float2* zrow = P.needs_raw_iq ? a.cplx + (static_cast<size_t>(stream) * a.n_iq_rows + P.iq_row) * a.plane_stride : nullptr;
+    float* __restrict__ wmain = a.wmain + static_cast<size_t>(row) * a.wmain_stride;
+    float* __restrict__ carry = a.carry + static_cast<size_t>(row) * kAgcExtra;
+    float2* __restrict__ iqo = (a.iq_out && P.has_iq_outputs) ? a.iq_out + static_cast<size_t>(row) * a.iq_out_stride : nullptr;
+    const uint32_t n = a.nsteps;
+    // virtual waveout: index v in [0, n) is emitted audio, [n, n+AGC_EXTRA) is the lookahead kept in `carry`
+    auto W = [&](uint32_t v) -> float& { return v < n ? wmain[v] : carry[v - n]; };
+
+    // the lookahead of the previous call is the head of this call's emitted audio (output.cpp:948)
+    for (int v = 0; v < kAgcExtra; ++v)
+        wmain[v] = carry[v];
+
+    const bool am = P.modulation == MI_MOD_AM;
+    const float ampfactor = P.ampfactor;
+    bool batch_open = false;
+    uint32_t in_batch = 0, batch = 0;
+
+    // Inputs of step i+2 are requested while step i runs (a two-deep software pipeline in named
+    // registers): the loop's serial chain is arithmetic only.  Index clamped at the row end.
+    const uint32_t last = n - 1;
+    float sx1 = magrow[kAgcExtra], ax1 = magrow[0];
+    float sx2 = magrow[kAgcExtra + 1], ax2 = magrow[1];
+    float2 zx1 = make_float2(0.0f, 0.0f), zx2 = zx1;
+    if (zrow) {
+        zx1 = zrow[0];
+        zx2 = zrow[1];
+    }
+
+    {
+        for (uint32_t i = 0; i < n; ++i) {
+            float x = sx1;  // wavein[j]
+            const float ax = ax1;  // wavein[j - AGC_EXTRA]
+            float re = zx1.x, im = zx1.y;  // iq_in[2*(j-AGC_EXTRA)], [+1]
+            sx1 = sx2;
+            ax1 = ax2;
+            zx1 = zx2;
+            {
+                const uint32_t nxt = (i + 2 <= last) ? i + 2 : last;
+                sx2 = magrow[kAgcExtra + nxt];
+                ax2 = magrow[nxt];
+                if (zrow)
+                    zx2 = zrow[nxt];
+            }
+
+            process_raw(c, x);  // rtl_airband.cpp:529
+
+            if (zrow && should_filter(c)) {  // rtl_airband.cpp:532-552
+                const uint32_t idx = c.s.dm_phi >> 16;  // sincosf_lut, util.cpp:113-127
+                const float fract = static_cast<float>(c.s.dm_phi & 0xffff) / 65536.0f;
+                float v1 = a.sin_lut[idx], v2 = a.sin_lut[idx + 1];
+                const float swf = v1 + (v2 - v1) * fract;
+                v1 = a.cos_lut[idx];
+                v2 = a.cos_lut[idx + 1];
+                const float cwf = v1 + (v2 - v1) * fract;
+                const float nswf = -swf;  // multiply(real, imag, cwf, -swf), rtl_airband.cpp:141-144
+                float re_tmp = re * cwf - im * nswf;
+                float im_tmp = im * cwf + re * nswf;
+                c.s.dm_phi = (c.s.dm_phi + P.dm_dphi) & 0xffffffu;
+                if (P.lowpass_enabled) {  // LowpassFilter::apply, filters.cpp:146-163
+                    ChanState& s = c.s;
+                    s.lp_xr[0] = s.lp_xr[1], s.lp_xi[0] = s.lp_xi[1];
+                    s.lp_xr[1] = s.lp_xr[2], s.lp_xi[1] = s.lp_xi[2];
+                    s.lp_xr[2] = re_tmp / P.lowpass_gain;
+                    s.lp_xi[2] = im_tmp / P.lowpass_gain;
+                    s.lp_yr[0] = s.lp_yr[1], s.lp_yi[0] = s.lp_yi[1];
+                    s.lp_yr[1] = s.lp_yr[2], s.lp_yi[1] = s.lp_yi[2];
+                    s.lp_yr[2] = (s.lp_xr[0] + s.lp_xr[2]) + (2.0f * s.lp_xr[1]) + (P.lowpass_yc0 * s.lp_yr[0]) + (P.lowpass_yc1 * s.lp_yr[1]);
+                    s.lp_yi[2] = (s.lp_xi[0] + s.lp_xi[2]) + (2.0f * s.lp_xi[1]) + (P.lowpass_yc0 * s.lp_yi[0]) + (P.lowpass_yc1 * s.lp_yi[1]);
+                    re_tmp = s.lp_yr[2];
+                    im_tmp = s.lp_yi[2];
+                }
+                re = re_tmp;
+                im = im_tmp;
+                x = sqrtf(re * re + im * im);
+                magrow[kAgcExtra + i] = x;  // channel->wavein[j] is overwritten and read again AGC_EXTRA steps later
+                if (P.lowpass_enabled)
+                    process_filtered(c, x);
+            }
+
+            if (am) {  // rtl_airband.cpp:554-569
+                if (c.s.current_state != SQ_OPEN && c.s.next_state == SQ_OPEN) {  // first_open_sample
+                    for (int kk = 0; kk < kAgcExtra; ++kk) {
+                        const float w = magrow[i + kk];
+                        if (w >= squelch_level(c))
+                            c.s.agcavgfast = c.s.agcavgfast * 0.9f + w * 0.1f;
+                    }
+                } else if ((c.s.current_state == SQ_CLOSING && c.s.next_state == SQ_CLOSED) ||
+                           (c.s.current_state != SQ_LOW_SIGNAL_ABORT && c.s.next_state == SQ_LOW_SIGNAL_ABORT)) {  // last_open_sample
+                    float v = W(i);
+                    for (int kk = 1; kk < kAgcExtra; ++kk) {
+                        v = v * 0.94f;
+                        W(i + kk) = v;
+                    }
+                }
+            }
+
+            float wout = 0.0f;
+            if (c.s.current_state == SQ_OPEN || c.s.current_state == SQ_CLOSING) {  // should_process_audio
+                if (am) {  // rtl_airband.cpp:575-585
+                    if (x > squelch_level(c))
+                        c.s.agcavgfast = c.s.agcavgfast * 0.995f + x * 0.005f;
+                    wout = (ax - c.s.agcavgfast) / (c.s.agcavgfast * 1.5f);
+                    if (fabsf(wout) > 0.8f) {
+                        wout *= 0.85f;
+                        c.s.agcavgfast *= 1.15f;
+                    }
+                } else {  // NFM, rtl_airband.cpp:587-604
+                    if (!a.fm_quadri) {
+                        const float nbj = -c.s.pj;  // polar_disc_fast: multiply(ar, aj, br, -bj)
+                        const float cr = re * c.s.pr - im * nbj;
+                        const float cj = im * c.s.pr + re * nbj;
+                        wout = static_cast<float>(static_cast<double>(fast_atan2(cj, cr)) * M_1_PI);
+                    } else {  // fm_quadri_demod
+                        wout = static_cast<float>(static_cast<double>((c.s.pr * im - re * c.s.pj) / (re * re + im * im + 1.0f)) * M_1_PI);
+                    }
+                    c.s.pr = re;
+                    c.s.pj = im;
+                    c.s.agcavgfast = c.s.agcavgfast * 0.995f + wout * 0.005f;
+                    wout -= c.s.agcavgfast;
+                    wout = wout * P.one_minus_alpha + c.s.prev_waveout * P.alpha;
+                    c.s.prev_waveout = wout;
+                }
+                process_audio(c, wout);  // rtl_airband.cpp:608
+            }
+
+            if (is_open(c)) {  // rtl_airband.cpp:612-641
+                if (P.notch_enabled) {  // NotchFilter::apply, filters.cpp:50-64
+                    ChanState& s = c.s;
+                    s.notch_x[0] = s.notch_x[1];
+                    s.notch_x[1] = s.notch_x[2];
+                    s.notch_x[2] = wout;
+                    s.notch_y[0] = s.notch_y[1];
+                    s.notch_y[1] = s.notch_y[2];
+                    s.notch_y[2] = P.notch_d0 * s.notch_x[2] - P.notch_d1 * s.notch_x[1] + P.notch_d0 * s.notch_x[0] + P.notch_d1 * s.notch_y[1] -
+                                   P.notch_d2 * s.notch_y[0];
+                    wout = s.notch_y[2];
+                }
+                wout *= ampfactor;
+                if (wout != wout)
+                    wout = 0.0f;
+                else if (wout > 1.0f)
+                    wout = 1.0f;
+                else if (wout < -1.0f)
+                    wout = -1.0f;
+                batch_open = true;
+                if (iqo)
+                    iqo[i] = make_float2(re, im);
+            } else {
+                wout = 0.0f;
+                if (iqo)
+                    iqo[i] = make_float2(0.0f, 0.0f);
+            }
+            W(kAgcExtra + i) = wout;
+
+            if (++in_batch == kWaveBatch) {  // rtl_airband.cpp:523,628,667-669
+                a.axc[static_cast<size_t>(row) * a.nbatches + batch] = batch_open ? MI_SIGNAL : MI_NO_SIGNAL;
+                if (batch_open)
+                    c.s.active_counter++;
+                batch_open = false;
+                in_batch = 0;
+                batch++;
+            }
+        }
+    }
+
+    // plane carry: the last AGC_EXTRA (possibly low-pass-rewritten) magnitudes and raw bins move to the front,
+    // the reference's memmove (rtl_airband.cpp:643-646)
+    for (int v = 0; v < kAgcExtra; ++v)
+        magrow[v] = magrow[n + v];
+    if (zrow) {
+        float2* zw = a.cplx + (static_cast<size_t>(stream) * a.n_iq_rows + P.iq_row) * a.plane_stride;
+        for (int v = 0; v < kAgcExtra; ++v)
+            zw[v] = zw[n + v];
+    }
+
+    a.st[row] = c.s;
+    if (a.stats) {  // what output.cpp:634-811 reads through the Squelch getters
+        mi_channel_stats st;
+        st.noise_level = c.s.noise_floor;
+        st.signal_level = c.s.pre_full;
+        float lvl;
+        if (P.using_manual_level)
+            lvl = P.manual_signal_level;
+        else if (c.s.squelch_level_cache != 0.0f)
+            lvl = c.s.squelch_level_cache;
+        else
+            lvl = ((flapping(c) && P.flappy_signal_ratio < P.normal_signal_ratio) ? P.flappy_signal_ratio : P.normal_signal_ratio) * c.s.noise_floor;
+        st.squelch_level = lvl;
+        st.agcavgfast = c.s.agcavgfast;
+        st.open_count = c.s.open_count;
+        st.flappy_count = c.s.flappy_count;
+        st.ctcss_count = c.s.cs_found;
+        st.no_ctcss_count = c.s.cs_not_found;
+        st.active_counter = c.s.active_counter;
+        st.squelch_state = c.s.current_state;
+        const bool pre = c.s.pre_capped >= lvl;
+        const bool post = c.s.using_post_filter && c.s.post_capped >= c.ring[c.s.buffer_tail];
+        st.signal_outside_filter = (c.s.using_post_filter && pre && !post) ? 1 : 0;
+        a.stats[row] = st;
+    }
+}
+
+__global__ void k_init_state(ChanState* st, float* carry, float* sq_ring, float* ctcss_q, const ChanParams* cp, int nstreams, int nch,
+                             int n_ctcss_rows) {
+    const int rows = nstreams * nch;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gsz = gridDim.x * blockDim.x;
+    for (int row = gid; row < rows; row += gsz) {
+        const ChanParams& p = cp[row % nch];
+        ChanState s;
+        memset(&s, 0, sizeof(s));
+        s.noise_floor = 5.0f;  // Squelch::Squelch, squelch.cpp:36-70
+        s.moving_avg_cap = p.using_manual_level ? p.manual_cap : p.cap_factor * s.noise_floor;
+        s.pre_full = s.pre_capped = 0.001f;
+        s.post_full = s.post_capped = 0.001f;
+        s.squelch_level_cache = 0.0f;
+        s.next_state = s.current_state = SQ_CLOSED;
+        s.sample_count = 0xffffffffu;  // sample_count_ = -1
+        s.buffer_head = 0;
+        s.buffer_tail = 1;
+        s.agcavgfast = 0.5f;    // mk_freqlist, config.cpp:280
+        s.prev_waveout = 0.5f;  // config.cpp:332
+        st[row] = s;
+    }
+    for (int i = gid; i < rows * kAgcExtra; i += gsz)
+        carry[i] = 0.5f;  // channel->waveout[k] = 0.5, config.cpp:321
+    for (int i = gid; i < rows * kSquelchRing; i += gsz)
+        sq_ring[i] = 0.0f;
+    for (size_t i = gid; i < static_cast<size_t>(nstreams) * n_ctcss_rows * 4 * kMaxTones; i += gsz)
+        ctcss_q[i] = 0.0f;
+}
+
+__global__ void k_iqgen(const IqGenDerived* __restrict__ cfg, const int16_t* __restrict__ tab, uint32_t first_stream, size_t stream_stride,
+                        uint64_t first, uint64_t count, unsigned char* __restrict__ out) {
+    __shared__ IqGenDerived g;
+    __shared__ int16_t stab[1024];
+    for (unsigned i = threadIdx.x; i < sizeof(IqGenDerived) / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(&g)[i] = reinterpret_cast<const uint32_t*>(cfg)[i];
+    for (unsigned i = threadIdx.x; i < 1024; i += blockDim.x)
+        stab[i] = tab[i];
+    __syncthreads();
+    const uint32_t stream = blockIdx.y;
+    unsigned char* dst = out + static_cast<size_t>(stream) * stream_stride;
+    // 8 complex samples (16 bytes) per lane per iteration
+    const uint64_t ngroups = (count + 7) / 8;
+    for (uint64_t grp = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; grp < ngroups; grp += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        unsigned char b[16];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            iq_sample(g, stab, first_stream + stream, first + grp * 8 + k, b + 2 * k);
+        if (grp * 8 + 8 <= count) {
+            *reinterpret_cast<uint4*>(dst + grp * 16) = *reinterpret_cast<uint4*>(b);
+        } else {
+            for (uint64_t k = 0; grp * 8 + k < count; ++k) {
+                dst[grp * 16 + 2 * k] = b[2 * k];
+                dst[grp * 16 + 2 * k + 1] = b[2 * k + 1];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_demod(const DemodArgs& a, hipStream_t s) {
+    const int rows = a.nstreams * a.nch;
+    if (rows == 0 || a.nsteps == 0)
+        return hipSuccess;
+    const int blocks = (rows + a.lanes_per_wave - 1) / a.lanes_per_wave;
+    hipLaunchKernelGGL(k_demod, dim3(blocks), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_init_state(ChanState* st, float* carry, float* sq_ring, float* ctcss_q, const ChanParams* cp, int nstreams, int nch,
+                             int n_ctcss_rows, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_state, dim3(64), dim3(256), 0, s, st, carry, sq_ring, ctcss_q, cp, nstreams, nch, n_ctcss_rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_iqgen(const IqGenDerived* d_cfg, const int16_t* d_tab, uint32_t first_stream, uint32_t nstreams, size_t stream_stride,
+                        uint64_t first, uint64_t count, unsigned char* d_out, hipStream_t s) {
+    if (count == 0 || nstreams == 0)
+        return hipSuccess;
+    const uint64_t ngroups = (count + 7) / 8;
+    const unsigned bx = static_cast<unsigned>(ngroups / 256 + 1 > 4096 ? 4096 : ngroups / 256 + 1);
+    hipLaunchKernelGGL(k_iqgen, dim3(bx, nstreams), dim3(256), 0, s, d_cfg, d_tab, first_stream, stream_stride, first, count, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace mi

@@ -1,0 +1,94 @@
+// kernels.hpp -- launch interfaces and device-resident structs shared by the .hip files and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "iqgen.hpp"
+#include "plan.hpp"
+
+namespace mi {
+
+// Complete DSP state of one (stream, channel): everything freq_t / channel_t / Squelch / filters carry
+// from one batch to the next in the reference.  4- and 8-byte PODs only; it is the checkpoint blob too.
+struct ChanState {
+    // Squelch (squelch.h:117-158)
+    float noise_floor;
+    float moving_avg_cap;
+    float pre_full, pre_capped;
+    float post_full, post_capped;
+    float squelch_level_cache;
+    int32_t using_post_filter;
+    int32_t next_state, current_state;
+    int32_t delay;
+    int32_t low_signal_count;
+    uint32_t sample_count;  // only sample_count % 16 is ever observed (squelch.cpp:212)
+    uint32_t recent_open_count, closed_sample_count;
+    int32_t buffer_head, buffer_tail;
+    uint64_t open_count, flappy_count;
+    // CTCSS fast / slow (ctcss.h:86-97); detector q1/q2 live in the ctcss_q table
+    int32_t cf_enough, cf_count, cf_has_tone;
+    int32_t cs_enough, cs_count, cs_has_tone;
+    uint64_t cf_found, cf_not_found, cs_found, cs_not_found;
+    // freq_t / channel_t (boondock_airband.h:232-262)
+    float agcavgfast;
+    float pr, pj, prev_waveout;
+    uint32_t dm_phi;
+    uint32_t pad0;
+    uint64_t active_counter;
+    // NotchFilter x/y, LowpassFilter xv/yv (filters.h:33-61)
+    float notch_x[3], notch_y[3];
+    float lp_xr[3], lp_xi[3], lp_yr[3], lp_yi[3];
+};
+
+struct ChannelizeArgs {
+    const unsigned char* iq;  // stream s at iq + s*stream_stride
+    size_t stream_stride;
+    size_t valid_bytes;       // readable bytes per stream starting at its base
+    uint32_t hop_bytes;
+    uint32_t nfft;            // windows per stream in this launch
+    float* mag;               // [nstreams*nch][plane_stride]
+    float2* cplx;             // [nstreams*n_iq_rows][plane_stride]
+    size_t plane_stride;
+    uint32_t plane_off;       // plane index of window 0
+    const float* window;
+    const float* tw;
+    const float* levels;
+    float conv_scale;
+    const ChanParams* cp;
+    int nch, n_iq_rows;
+};
+
+struct DemodArgs {
+    int nstreams, nch, n_iq_rows, n_ctcss_rows;
+    uint32_t nsteps;    // samples per channel in this launch (multiple of WAVE_BATCH)
+    uint32_t nbatches;
+    float* mag;         // [rows][plane_stride]; index AGC_EXTRA+i is the squelch sample of step i
+    float2* cplx;
+    size_t plane_stride;
+    float* wmain;       // emitted audio, [rows][wmain_stride], nsteps valid
+    size_t wmain_stride;
+    float* carry;       // [rows][AGC_EXTRA]: lookahead carried between calls
+    float2* iq_out;     // [rows][iq_out_stride] or null
+    size_t iq_out_stride;
+    char* axc;          // [rows][nbatches]
+    const ChanParams* cp;
+    ChanState* st;      // [rows]
+    const float* sin_lut;  // 257
+    const float* cos_lut;  // 257
+    float* sq_ring;        // [rows][kSquelchRing] (only read/written for low-pass channels)
+    const float* ctcss_coeff;  // [n_ctcss_rows][2][kMaxTones]
+    float* ctcss_q;            // [nstreams][n_ctcss_rows][2][2][kMaxTones]
+    mi_channel_stats* stats;   // [rows]
+    int fm_quadri;
+    int lanes_per_wave;
+};
+
+hipError_t launch_channelize(const ChannelizeArgs& a, int log2n, int sfmt, int nstreams, hipStream_t s);
+hipError_t launch_demod(const DemodArgs& a, hipStream_t s);
+hipError_t launch_init_state(ChanState* st, float* carry, float* sq_ring, float* ctcss_q, const ChanParams* cp, int nstreams, int nch,
+                             int n_ctcss_rows, hipStream_t s);
+hipError_t launch_iqgen(const IqGenDerived* d_cfg, const int16_t* d_tab, uint32_t first_stream, uint32_t nstreams, size_t stream_stride,
+                        uint64_t first, uint64_t count, unsigned char* d_out, hipStream_t s);
+
+}  // namespace mi

@@ -1,0 +1,660 @@
+// mi_airband.cpp -- the C ABI of include/mi_airband.h over the HIP kernels.
+// No CPU fallback exists: without a HIP device every compute entry point fails with MI_ERR_NO_DEVICE.
+#include "../../include/mi_airband.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "plan.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& what) {
+    g_err = what;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* where) {
+    g_err = std::string(where) + ": " + hipGetErrorString(e);
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? MI_ERR_NO_DEVICE : (e == hipErrorOutOfMemory ? MI_ERR_NOMEM : MI_ERR_HIP);
+}
+
+#define HIP_TRY(expr)                      \
+    do {                                   \
+        hipError_t e__ = (expr);           \
+        if (e__ != hipSuccess)             \
+            return hip_fail(e__, #expr);   \
+    } while (0)
+
+template <class T>
+hipError_t dalloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0)
+        return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+}
+
+}  // namespace
+
+struct mi_plan {
+    mi::Plan plan;
+};
+
+struct mi_demod {
+    mi::Plan plan;
+    int gpu = 0;
+    int nstreams = 0, nch = 0, rows = 0, max_batches = 0;
+    bool first_call = true;  // waveend starts at 0: the first batch needs AGC_EXTRA more windows (config.cpp:808)
+    size_t plane_stride = 0;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    // device memory
+    float* d_window = nullptr;
+    float* d_tw = nullptr;
+    float* d_levels = nullptr;
+    float* d_sin = nullptr;
+    float* d_cos = nullptr;
+    mi::ChanParams* d_cp = nullptr;
+    mi::ChanState* d_state = nullptr;
+    float* d_mag = nullptr;
+    float2* d_cplx = nullptr;
+    float* d_carry = nullptr;
+    float* d_ring = nullptr;
+    float* d_ctcss_coeff = nullptr;
+    float* d_ctcss_q = nullptr;
+    mi_channel_stats* d_stats = nullptr;
+    // staging for the host-buffer entry
+    unsigned char* d_iq = nullptr;
+    size_t iq_stride = 0;
+    float* d_wout = nullptr;
+    float2* d_iqout = nullptr;
+    char* d_axc = nullptr;
+    unsigned char* h_pin = nullptr;  // pinned bounce buffer for the IQ upload
+    size_t h_pin_bytes = 0;
+};
+
+namespace {
+
+int n_fft_for(const mi_demod* h, int nbatches) {
+    return nbatches * mi::kWaveBatch + (h->first_call ? mi::kAgcExtra : 0);
+}
+
+int lanes_per_wave_for(int rows) {
+    // up to 1024 waves (4 per CU) keep one channel each; beyond that pack lanes
+    int lpw = (rows + 1023) / 1024;
+    if (lpw < 1)
+        lpw = 1;
+    if (lpw > 64)
+        lpw = 64;
+    return lpw;
+}
+
+// shared by both entry points; everything is enqueued on `s`
+int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t valid_bytes, int nbatches, float* d_wmain, size_t wmain_stride,
+            float2* d_iq_out, size_t iq_out_stride, char* d_axc, hipStream_t s) {
+    const int nfft = n_fft_for(h, nbatches);
+    mi::ChannelizeArgs ca{};
+    ca.iq = d_iq;
+    ca.stream_stride = stream_stride;
+    ca.valid_bytes = valid_bytes;
+    ca.hop_bytes = static_cast<uint32_t>(h->plan.hop_bytes);
+    ca.nfft = static_cast<uint32_t>(nfft);
+    ca.mag = h->d_mag;
+    ca.cplx = h->d_cplx;
+    ca.plane_stride = h->plane_stride;
+    ca.plane_off = h->first_call ? 0 : mi::kAgcExtra;
+    ca.window = h->d_window;
+    ca.tw = h->d_tw;
+    ca.levels = h->d_levels;
+    ca.conv_scale = h->plan.conv_scale;
+    ca.cp = h->d_cp;
+    ca.nch = h->nch;
+    ca.n_iq_rows = h->plan.n_iq_rows;
+
+    mi::DemodArgs da{};
+    da.nstreams = h->nstreams;
+    da.nch = h->nch;
+    da.n_iq_rows = h->plan.n_iq_rows;
+    da.n_ctcss_rows = h->plan.n_ctcss_rows;
+    da.nsteps = static_cast<uint32_t>(nbatches) * mi::kWaveBatch;
+    da.nbatches = static_cast<uint32_t>(nbatches);
+    da.mag = h->d_mag;
+    da.cplx = h->d_cplx;
+    da.plane_stride = h->plane_stride;
+    da.wmain = d_wmain;
+    da.wmain_stride = wmain_stride;
+    da.carry = h->d_carry;
+    da.iq_out = d_iq_out;
+    da.iq_out_stride = iq_out_stride;
+    da.axc = d_axc;
+    da.cp = h->d_cp;
+    da.st = h->d_state;
+    da.sin_lut = h->d_sin;
+    da.cos_lut = h->d_cos;
+    da.sq_ring = h->d_ring;
+    da.ctcss_coeff = h->d_ctcss_coeff;
+    da.ctcss_q = h->d_ctcss_q;
+    da.stats = h->d_stats;
+    da.fm_quadri = h->plan.dev.fm_quadri;
+    da.lanes_per_wave = lanes_per_wave_for(h->rows);
+
+    HIP_TRY(hipEventRecord(h->ev[0], s));
+    HIP_TRY(mi::launch_channelize(ca, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, s));
+    HIP_TRY(hipEventRecord(h->ev[1], s));
+    HIP_TRY(mi::launch_demod(da, s));
+    HIP_TRY(hipEventRecord(h->ev[2], s));
+    h->ev_valid = true;
+    h->first_call = false;
+    return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mi_last_error(void) {
+    return g_err.c_str();
+}
+
+int mi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+void mi_demod_destroy(mi_demod* h) {
+    if (!h)
+        return;
+    (void)hipSetDevice(h->gpu);
+    void* ptrs[] = {h->d_window, h->d_tw,   h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_mag,   h->d_cplx, h->d_carry,
+                    h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc};
+    for (void* p : ptrs)
+        if (p)
+            (void)hipFree(p);
+    if (h->h_pin)
+        (void)hipHostFree(h->h_pin);
+    for (hipEvent_t e : h->ev)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (h->own_stream)
+        (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int nch, int nstreams, int max_batches, int gpu, mi_demod** out) {
+    if (!out)
+        return fail(MI_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!dev || !chans)
+        return fail(MI_ERR_INVALID, "dev/chans is NULL");
+    if (nstreams < 1 || max_batches < 1)
+        return fail(MI_ERR_INVALID, "nstreams and max_batches must be >= 1");
+    mi_demod* h = new (std::nothrow) mi_demod();
+    if (!h)
+        return fail(MI_ERR_NOMEM, "host allocation failed");
+    const char* msg = "";
+    int rc = mi::build_plan(*dev, chans, nch, h->plan, &msg);
+    if (rc != MI_OK) {
+        delete h;
+        return fail(rc, msg);
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) {
+        delete h;
+        return fail(MI_ERR_NO_DEVICE, "no HIP device: the MI355X path has no CPU fallback");
+    }
+    if (gpu < 0 || gpu >= ndev) {
+        delete h;
+        return fail(MI_ERR_INVALID, "gpu index out of range");
+    }
+    h->gpu = gpu;
+    h->nstreams = nstreams;
+    h->nch = nch;
+    h->rows = nstreams * nch;
+    h->max_batches = max_batches;
+    const mi::Plan& p = h->plan;
+    const size_t max_steps = static_cast<size_t>(max_batches) * mi::kWaveBatch;
+    h->plane_stride = (max_steps + 2 * mi::kAgcExtra + 3) & ~static_cast<size_t>(3);
+
+    auto bail = [&](int code) {
+        std::string keep = g_err;
+        mi_demod_destroy(h);
+        g_err = keep;
+        return code;
+    };
+#define TRY_OR_BAIL(expr)                          \
+    do {                                           \
+        hipError_t e__ = (expr);                   \
+        if (e__ != hipSuccess)                     \
+            return bail(hip_fail(e__, #expr));     \
+    } while (0)
+
+    TRY_OR_BAIL(hipSetDevice(gpu));
+    TRY_OR_BAIL(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    for (auto& ev : h->ev)
+        TRY_OR_BAIL(hipEventCreate(&ev));
+    const size_t rows = static_cast<size_t>(h->rows);
+    TRY_OR_BAIL(dalloc(&h->d_window, p.window.size()));
+    TRY_OR_BAIL(dalloc(&h->d_tw, p.tw.size()));
+    TRY_OR_BAIL(dalloc(&h->d_levels, 256));
+    TRY_OR_BAIL(dalloc(&h->d_sin, 257));
+    TRY_OR_BAIL(dalloc(&h->d_cos, 257));
+    TRY_OR_BAIL(dalloc(&h->d_cp, static_cast<size_t>(nch)));
+    TRY_OR_BAIL(dalloc(&h->d_state, rows));
+    TRY_OR_BAIL(dalloc(&h->d_mag, rows * h->plane_stride));
+    TRY_OR_BAIL(dalloc(&h->d_cplx, static_cast<size_t>(nstreams) * p.n_iq_rows * h->plane_stride));
+    TRY_OR_BAIL(dalloc(&h->d_carry, rows * mi::kAgcExtra));
+    TRY_OR_BAIL(dalloc(&h->d_ring, rows * mi::kSquelchRing));
+    TRY_OR_BAIL(dalloc(&h->d_ctcss_coeff, p.ctcss_coeff.size()));
+    TRY_OR_BAIL(dalloc(&h->d_ctcss_q, static_cast<size_t>(nstreams) * p.n_ctcss_rows * 4 * mi::kMaxTones));
+    TRY_OR_BAIL(dalloc(&h->d_stats, rows));
+    TRY_OR_BAIL(hipMemcpy(h->d_window, p.window.data(), p.window.size() * 4, hipMemcpyHostToDevice));
+    TRY_OR_BAIL(hipMemcpy(h->d_tw, p.tw.data(), p.tw.size() * 4, hipMemcpyHostToDevice));
+    TRY_OR_BAIL(hipMemcpy(h->d_levels, p.levels.data(), 256 * 4, hipMemcpyHostToDevice));
+    TRY_OR_BAIL(hipMemcpy(h->d_sin, p.sin_lut, 257 * 4, hipMemcpyHostToDevice));
+    TRY_OR_BAIL(hipMemcpy(h->d_cos, p.cos_lut, 257 * 4, hipMemcpyHostToDevice));
+    TRY_OR_BAIL(hipMemcpy(h->d_cp, p.cp.data(), p.cp.size() * sizeof(mi::ChanParams), hipMemcpyHostToDevice));
+    if (!p.ctcss_coeff.empty())
+        TRY_OR_BAIL(hipMemcpy(h->d_ctcss_coeff, p.ctcss_coeff.data(), p.ctcss_coeff.size() * 4, hipMemcpyHostToDevice));
+    TRY_OR_BAIL(hipMemset(h->d_mag, 0, rows * h->plane_stride * 4));
+    if (h->d_cplx)
+        TRY_OR_BAIL(hipMemset(h->d_cplx, 0, static_cast<size_t>(nstreams) * p.n_iq_rows * h->plane_stride * 8));
+    TRY_OR_BAIL(hipMemset(h->d_stats, 0, rows * sizeof(mi_channel_stats)));
+    TRY_OR_BAIL(mi::launch_init_state(h->d_state, h->d_carry, h->d_ring, h->d_ctcss_q, h->d_cp, nstreams, nch, p.n_ctcss_rows, h->own_stream));
+    TRY_OR_BAIL(hipStreamSynchronize(h->own_stream));
+#undef TRY_OR_BAIL
+    *out = h;
+    return MI_OK;
+}
+
+size_t mi_demod_hop_bytes(const mi_demod* h) {
+    return h ? h->plan.hop_bytes : 0;
+}
+
+size_t mi_demod_bytes_needed(const mi_demod* h, int nbatches) {
+    if (!h || nbatches < 1)
+        return 0;
+    const size_t nfft = static_cast<size_t>(n_fft_for(h, nbatches));
+    return (nfft - 1) * h->plan.hop_bytes + 2 * static_cast<size_t>(h->plan.bytes_per_sample) * h->plan.fft_size;
+}
+
+size_t mi_demod_bytes_consumed(const mi_demod* h, int nbatches) {
+    if (!h || nbatches < 1)
+        return 0;
+    return static_cast<size_t>(n_fft_for(h, nbatches)) * h->plan.hop_bytes;
+}
+
+int mi_demod_process_device(mi_demod* h, const void* d_iq, size_t stream_stride_bytes, int nbatches, float* d_waveout, float* d_iq_out,
+                            char* d_axc, void* hip_stream) {
+    if (!h || !d_iq || !d_waveout || !d_axc)
+        return fail(MI_ERR_INVALID, "NULL argument");
+    if (nbatches < 1 || nbatches > h->max_batches)
+        return fail(MI_ERR_INVALID, "nbatches out of range for this handle");
+    const size_t align = 2 * static_cast<size_t>(h->plan.bytes_per_sample);
+    if (reinterpret_cast<uintptr_t>(d_iq) % align != 0 || stream_stride_bytes % align != 0)
+        return fail(MI_ERR_INVALID, "IQ pointer and stride must be aligned to one complex sample");
+    const size_t need = mi_demod_bytes_needed(h, nbatches);
+    if (h->nstreams > 1 && stream_stride_bytes < need)
+        return fail(MI_ERR_INVALID, "stream stride shorter than the bytes one call reads");
+    HIP_TRY(hipSetDevice(h->gpu));
+    const size_t nsteps = static_cast<size_t>(nbatches) * mi::kWaveBatch;
+    return enqueue(h, static_cast<const unsigned char*>(d_iq), stream_stride_bytes, need, nbatches, d_waveout, nsteps,
+                   reinterpret_cast<float2*>(d_iq_out), nsteps, d_axc, static_cast<hipStream_t>(hip_stream));
+}
+
+int mi_demod_process(mi_demod* h, const uint8_t* const* iq, int nbatches, float* waveout, float* iq_out, char* axc, mi_channel_stats* stats) {
+    if (!h || !iq || !waveout || !axc)
+        return fail(MI_ERR_INVALID, "NULL argument");
+    if (nbatches < 1 || nbatches > h->max_batches)
+        return fail(MI_ERR_INVALID, "nbatches out of range for this handle");
+    HIP_TRY(hipSetDevice(h->gpu));
+    const size_t rows = static_cast<size_t>(h->rows);
+    const size_t nsteps = static_cast<size_t>(nbatches) * mi::kWaveBatch;
+    if (!h->d_iq) {  // staging sized for the largest call, allocated on first use
+        const size_t max_fft = static_cast<size_t>(h->max_batches) * mi::kWaveBatch + mi::kAgcExtra;
+        h->iq_stride = ((max_fft - 1) * h->plan.hop_bytes + 2 * static_cast<size_t>(h->plan.bytes_per_sample) * h->plan.fft_size + 255) & ~static_cast<size_t>(255);
+        HIP_TRY(dalloc(&h->d_iq, h->iq_stride * h->nstreams));
+        HIP_TRY(dalloc(&h->d_wout, rows * static_cast<size_t>(h->max_batches) * mi::kWaveBatch));
+        HIP_TRY(dalloc(&h->d_iqout, rows * static_cast<size_t>(h->max_batches) * mi::kWaveBatch));
+        HIP_TRY(dalloc(&h->d_axc, rows * static_cast<size_t>(h->max_batches)));
+        h->h_pin_bytes = h->iq_stride * h->nstreams;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), h->h_pin_bytes, hipHostMallocDefault));
+    }
+    const size_t need = mi_demod_bytes_needed(h, nbatches);
+    hipStream_t s = h->own_stream;
+    for (int i = 0; i < h->nstreams; ++i) {
+        if (!iq[i])
+            return fail(MI_ERR_INVALID, "NULL stream pointer");
+        std::memcpy(h->h_pin + static_cast<size_t>(i) * h->iq_stride, iq[i], need);
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_iq, h->h_pin, h->iq_stride * (h->nstreams - 1) + need, hipMemcpyHostToDevice, s));
+    int rc = enqueue(h, h->d_iq, h->iq_stride, need, nbatches, h->d_wout, nsteps, iq_out ? h->d_iqout : nullptr, nsteps, h->d_axc, s);
+    if (rc != MI_OK)
+        return rc;
+    // host layout: [rows][nsteps + AGC_EXTRA] = emitted audio followed by the lookahead (channel_t.waveout)
+    const size_t hstride = (nsteps + mi::kAgcExtra) * sizeof(float);
+    HIP_TRY(hipMemcpy2DAsync(waveout, hstride, h->d_wout, nsteps * sizeof(float), nsteps * sizeof(float), rows, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpy2DAsync(waveout + nsteps, hstride, h->d_carry, mi::kAgcExtra * sizeof(float), mi::kAgcExtra * sizeof(float), rows,
+                             hipMemcpyDeviceToHost, s));
+    if (iq_out) {
+        for (size_t r = 0; r < rows; ++r) {
+            if (!h->plan.cp[r % h->nch].has_iq_outputs)
+                continue;
+            HIP_TRY(hipMemcpyAsync(iq_out + r * nsteps * 2, h->d_iqout + r * nsteps, nsteps * sizeof(float2), hipMemcpyDeviceToHost, s));
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(axc, h->d_axc, rows * nbatches, hipMemcpyDeviceToHost, s));
+    if (stats)
+        HIP_TRY(hipMemcpyAsync(stats, h->d_stats, rows * sizeof(mi_channel_stats), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return MI_OK;
+}
+
+int mi_demod_get_stats(mi_demod* h, mi_channel_stats* stats) {
+    if (!h || !stats)
+        return fail(MI_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->gpu));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(stats, h->d_stats, static_cast<size_t>(h->rows) * sizeof(mi_channel_stats), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+// ---- checkpoint: [header][ChanState rows][carry][ring][ctcss_q][mag head][cplx head] ----
+namespace {
+struct StateHeader {
+    uint32_t magic, rows, nch, n_iq_rows, n_ctcss_rows, first_call, fft_log, pad;
+};
+size_t state_bytes(const mi_demod* h) {
+    const size_t rows = static_cast<size_t>(h->rows);
+    return sizeof(StateHeader) + rows * sizeof(mi::ChanState) + rows * mi::kAgcExtra * 4 + rows * mi::kSquelchRing * 4 +
+           static_cast<size_t>(h->nstreams) * h->plan.n_ctcss_rows * 4 * mi::kMaxTones * 4 + rows * mi::kAgcExtra * 4 +
+           static_cast<size_t>(h->nstreams) * h->plan.n_iq_rows * mi::kAgcExtra * 8;
+}
+}  // namespace
+
+size_t mi_demod_state_size(const mi_demod* h) {
+    return h ? state_bytes(h) : 0;
+}
+
+int mi_demod_get_state(mi_demod* h, void* buf, size_t len) {
+    if (!h || !buf || len < state_bytes(h))
+        return fail(MI_ERR_INVALID, "state buffer too small");
+    HIP_TRY(hipSetDevice(h->gpu));
+    HIP_TRY(hipDeviceSynchronize());
+    auto* o = static_cast<unsigned char*>(buf);
+    StateHeader hd{0x4d494142u, static_cast<uint32_t>(h->rows), static_cast<uint32_t>(h->nch), static_cast<uint32_t>(h->plan.n_iq_rows),
+                   static_cast<uint32_t>(h->plan.n_ctcss_rows), h->first_call ? 1u : 0u, static_cast<uint32_t>(h->plan.log2n), 0};
+    std::memcpy(o, &hd, sizeof(hd));
+    o += sizeof(hd);
+    const size_t rows = static_cast<size_t>(h->rows);
+    auto pull = [&](const void* d, size_t bytes) -> hipError_t {
+        if (bytes == 0)
+            return hipSuccess;
+        hipError_t e = hipMemcpy(o, d, bytes, hipMemcpyDeviceToHost);
+        o += bytes;
+        return e;
+    };
+    HIP_TRY(pull(h->d_state, rows * sizeof(mi::ChanState)));
+    HIP_TRY(pull(h->d_carry, rows * mi::kAgcExtra * 4));
+    HIP_TRY(pull(h->d_ring, rows * mi::kSquelchRing * 4));
+    HIP_TRY(pull(h->d_ctcss_q, static_cast<size_t>(h->nstreams) * h->plan.n_ctcss_rows * 4 * mi::kMaxTones * 4));
+    HIP_TRY(hipMemcpy2D(o, mi::kAgcExtra * 4, h->d_mag, h->plane_stride * 4, mi::kAgcExtra * 4, rows, hipMemcpyDeviceToHost));
+    o += rows * mi::kAgcExtra * 4;
+    const size_t zrows = static_cast<size_t>(h->nstreams) * h->plan.n_iq_rows;
+    if (zrows)
+        HIP_TRY(hipMemcpy2D(o, mi::kAgcExtra * 8, h->d_cplx, h->plane_stride * 8, mi::kAgcExtra * 8, zrows, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_demod_set_state(mi_demod* h, const void* buf, size_t len) {
+    if (!h || !buf || len < state_bytes(h))
+        return fail(MI_ERR_INVALID, "state buffer too small");
+    const auto* o = static_cast<const unsigned char*>(buf);
+    StateHeader hd;
+    std::memcpy(&hd, o, sizeof(hd));
+    if (hd.magic != 0x4d494142u || hd.rows != static_cast<uint32_t>(h->rows) || hd.nch != static_cast<uint32_t>(h->nch) ||
+        hd.n_iq_rows != static_cast<uint32_t>(h->plan.n_iq_rows) || hd.n_ctcss_rows != static_cast<uint32_t>(h->plan.n_ctcss_rows) ||
+        hd.fft_log != static_cast<uint32_t>(h->plan.log2n))
+        return fail(MI_ERR_INVALID, "state blob does not match this handle's configuration");
+    o += sizeof(hd);
+    HIP_TRY(hipSetDevice(h->gpu));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t rows = static_cast<size_t>(h->rows);
+    auto push = [&](void* d, size_t bytes) -> hipError_t {
+        if (bytes == 0)
+            return hipSuccess;
+        hipError_t e = hipMemcpy(d, o, bytes, hipMemcpyHostToDevice);
+        o += bytes;
+        return e;
+    };
+    HIP_TRY(push(h->d_state, rows * sizeof(mi::ChanState)));
+    HIP_TRY(push(h->d_carry, rows * mi::kAgcExtra * 4));
+    HIP_TRY(push(h->d_ring, rows * mi::kSquelchRing * 4));
+    HIP_TRY(push(h->d_ctcss_q, static_cast<size_t>(h->nstreams) * h->plan.n_ctcss_rows * 4 * mi::kMaxTones * 4));
+    HIP_TRY(hipMemcpy2D(h->d_mag, h->plane_stride * 4, o, mi::kAgcExtra * 4, mi::kAgcExtra * 4, rows, hipMemcpyHostToDevice));
+    o += rows * mi::kAgcExtra * 4;
+    const size_t zrows = static_cast<size_t>(h->nstreams) * h->plan.n_iq_rows;
+    if (zrows)
+        HIP_TRY(hipMemcpy2D(h->d_cplx, h->plane_stride * 8, o, mi::kAgcExtra * 8, mi::kAgcExtra * 8, zrows, hipMemcpyHostToDevice));
+    h->first_call = hd.first_call != 0;
+    return MI_OK;
+}
+
+int mi_demod_read_planes(mi_demod* h, int stream, int ch, int first, int count, float* mag, float* iq) {
+    if (!h || !mag || stream < 0 || stream >= h->nstreams || ch < 0 || ch >= h->nch || first < 0 || count < 0 ||
+        static_cast<size_t>(first) + count > h->plane_stride)
+        return fail(MI_ERR_INVALID, "bad plane range");
+    HIP_TRY(hipSetDevice(h->gpu));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t row = static_cast<size_t>(stream) * h->nch + ch;
+    HIP_TRY(hipMemcpy(mag, h->d_mag + row * h->plane_stride + first, static_cast<size_t>(count) * 4, hipMemcpyDeviceToHost));
+    const int iq_row = h->plan.cp[ch].iq_row;
+    if (iq && iq_row >= 0) {
+        const size_t zrow = static_cast<size_t>(stream) * h->plan.n_iq_rows + iq_row;
+        HIP_TRY(hipMemcpy(iq, h->d_cplx + zrow * h->plane_stride + first, static_cast<size_t>(count) * 8, hipMemcpyDeviceToHost));
+    }
+    return MI_OK;
+}
+
+int mi_demod_last_kernel_ms(mi_demod* h, float* channelize_ms, float* demod_ms) {
+    if (!h || !h->ev_valid)
+        return fail(MI_ERR_INVALID, "no call has been timed yet");
+    HIP_TRY(hipSetDevice(h->gpu));
+    HIP_TRY(hipEventSynchronize(h->ev[2]));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+    if (channelize_ms)
+        *channelize_ms = a;
+    if (demod_ms)
+        *demod_ms = b;
+    return MI_OK;
+}
+
+// ---------------- host-only plan views ----------------
+
+int mi_plan_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int nch, mi_plan** out) {
+    if (!out || !dev)
+        return fail(MI_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    mi_plan* p = new (std::nothrow) mi_plan();
+    if (!p)
+        return fail(MI_ERR_NOMEM, "host allocation failed");
+    const char* msg = "";
+    int rc = mi::build_plan(*dev, chans, nch, p->plan, &msg);
+    if (rc != MI_OK) {
+        delete p;
+        return fail(rc, msg);
+    }
+    *out = p;
+    return MI_OK;
+}
+
+void mi_plan_destroy(mi_plan* p) {
+    delete p;
+}
+
+int mi_plan_fft_size(const mi_plan* p) {
+    return p ? p->plan.fft_size : 0;
+}
+
+int mi_plan_window(const mi_plan* p, float* out) {
+    if (!p || !out)
+        return fail(MI_ERR_INVALID, "NULL argument");
+    std::memcpy(out, p->plan.window.data(), p->plan.window.size() * 4);
+    return MI_OK;
+}
+
+int mi_plan_twiddles(const mi_plan* p, float* out) {
+    if (!p || !out)
+        return fail(MI_ERR_INVALID, "NULL argument");
+    std::memcpy(out, p->plan.tw.data(), p->plan.tw.size() * 4);
+    return MI_OK;
+}
+
+int mi_plan_levels(const mi_plan* p, float* out) {
+    if (!p || !out)
+        return fail(MI_ERR_INVALID, "NULL argument");
+    std::memcpy(out, p->plan.levels.data(), 256 * 4);
+    return MI_OK;
+}
+
+int mi_plan_sincos_lut(const mi_plan* p, float* sin_out, float* cos_out) {
+    if (!p || !sin_out || !cos_out)
+        return fail(MI_ERR_INVALID, "NULL argument");
+    std::memcpy(sin_out, p->plan.sin_lut, 257 * 4);
+    std::memcpy(cos_out, p->plan.cos_lut, 257 * 4);
+    return MI_OK;
+}
+
+int mi_plan_channel(const mi_plan* p, int ch, mi_channel_derived* out) {
+    if (!p || !out || ch < 0 || ch >= p->plan.nch)
+        return fail(MI_ERR_INVALID, "bad channel index");
+    const mi::ChanParams& c = p->plan.cp[ch];
+    out->bin = c.bin;
+    out->dm_dphi = c.dm_dphi;
+    out->needs_raw_iq = c.needs_raw_iq;
+    out->has_iq_outputs = c.has_iq_outputs;
+    out->modulation = c.modulation;
+    out->using_manual_level = c.using_manual_level;
+    out->manual_signal_level = c.manual_signal_level;
+    out->normal_signal_ratio = c.normal_signal_ratio;
+    out->flappy_signal_ratio = c.flappy_signal_ratio;
+    out->ampfactor = c.ampfactor;
+    out->alpha = c.alpha;
+    out->notch_enabled = c.notch_enabled;
+    out->notch_d[0] = c.notch_d0;
+    out->notch_d[1] = c.notch_d1;
+    out->notch_d[2] = c.notch_d2;
+    out->lowpass_enabled = c.lowpass_enabled;
+    out->lowpass_gain = c.lowpass_gain;
+    out->lowpass_ycoeffs[0] = c.lowpass_yc0;
+    out->lowpass_ycoeffs[1] = c.lowpass_yc1;
+    out->ctcss_enabled = c.ctcss_enabled;
+    out->ctcss_fast_window = c.ctcss_fast_window;
+    out->ctcss_slow_window = c.ctcss_slow_window;
+    out->ctcss_fast_ndet = c.ctcss_fast_ndet;
+    out->ctcss_slow_ndet = c.ctcss_slow_ndet;
+    return MI_OK;
+}
+
+int mi_plan_ctcss_coeffs(const mi_plan* p, int ch, int slow, float* out) {
+    if (!p || !out || ch < 0 || ch >= p->plan.nch)
+        return fail(MI_ERR_INVALID, "bad channel index");
+    const mi::ChanParams& c = p->plan.cp[ch];
+    if (!c.ctcss_enabled)
+        return fail(MI_ERR_INVALID, "channel has no ctcss");
+    const float* base = p->plan.ctcss_coeff.data() + (static_cast<size_t>(c.ctcss_row) * 2 + (slow ? 1 : 0)) * mi::kMaxTones;
+    std::memcpy(out, base, static_cast<size_t>(slow ? c.ctcss_slow_ndet : c.ctcss_fast_ndet) * 4);
+    return MI_OK;
+}
+
+// ---------------- synthetic IQ ----------------
+
+int mi_iqgen_host(const mi_iqgen_cfg* cfg, uint32_t stream_id, uint64_t first, uint64_t count, uint8_t* out) {
+    if (!cfg || !out || cfg->ncarriers < 0 || cfg->ncarriers > 64 || cfg->sample_rate <= 0)
+        return fail(MI_ERR_INVALID, "bad iqgen configuration");
+    mi::IqGenDerived g;
+    mi::iqgen_derive(*cfg, g);
+    const int16_t* tab = mi::iqgen_sine_table();
+    for (uint64_t i = 0; i < count; ++i)
+        mi::iq_sample(g, tab, stream_id, first + i, out + 2 * i);
+    return MI_OK;
+}
+
+int mi_iqgen_device(const mi_iqgen_cfg* cfg, uint32_t first_stream_id, uint32_t nstreams, size_t stream_stride_bytes, uint64_t first,
+                    uint64_t count, void* d_out, void* hip_stream) {
+    if (!cfg || !d_out || cfg->ncarriers < 0 || cfg->ncarriers > 64 || cfg->sample_rate <= 0)
+        return fail(MI_ERR_INVALID, "bad iqgen configuration");
+    if (reinterpret_cast<uintptr_t>(d_out) % 16 != 0 || stream_stride_bytes % 16 != 0)
+        return fail(MI_ERR_INVALID, "iqgen output must be 16-byte aligned");
+    mi::IqGenDerived g;
+    mi::iqgen_derive(*cfg, g);
+    mi::IqGenDerived* d_cfg = nullptr;
+    int16_t* d_tab = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cfg), sizeof(g)));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_tab), 1024 * sizeof(int16_t));
+    if (e != hipSuccess) {
+        (void)hipFree(d_cfg);
+        return hip_fail(e, "hipMalloc");
+    }
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    int rc = MI_OK;
+    if ((e = hipMemcpy(d_cfg, &g, sizeof(g), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(d_tab, mi::iqgen_sine_table(), 1024 * sizeof(int16_t), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = mi::launch_iqgen(d_cfg, d_tab, first_stream_id, nstreams, stream_stride_bytes, first, count, static_cast<unsigned char*>(d_out), s)) !=
+            hipSuccess ||
+        (e = hipStreamSynchronize(s)) != hipSuccess)
+        rc = hip_fail(e, "mi_iqgen_device");
+    (void)hipFree(d_cfg);
+    (void)hipFree(d_tab);
+    return rc;
+}
+
+}  // extern "C"
+
+namespace mi {
+
+void iqgen_derive(const mi_iqgen_cfg& cfg, IqGenDerived& out) {
+    std::memset(&out, 0, sizeof(out));
+    out.seed = cfg.seed;
+    out.gate_samples = cfg.gate_samples;
+    out.noise_q8_mul = cfg.noise_q8_mul;
+    out.ncarriers = cfg.ncarriers;
+    const double turn = 4294967296.0;
+    for (int k = 0; k < cfg.ncarriers; ++k) {
+        const mi_iqgen_carrier& c = cfg.carriers[k];
+        const long long d = std::llround(static_cast<double>(c.offset_hz) / cfg.sample_rate * turn);
+        out.c[k].dphi = static_cast<uint32_t>(static_cast<uint64_t>(d));
+        out.c[k].dpsi_1k = static_cast<uint32_t>(std::llround(1000.0 / cfg.sample_rate * turn));
+        out.c[k].dpsi_100 = static_cast<uint32_t>(std::llround(100.0 / cfg.sample_rate * turn));
+        out.c[k].kind = c.kind;
+        out.c[k].amp_q8 = c.amp_q8;
+        out.c[k].gate_phase = c.gate_phase;
+    }
+}
+
+const int16_t* iqgen_sine_table() {
+    static int16_t tab[1024];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i < 1024; ++i)
+            tab[i] = static_cast<int16_t>(std::lround(32767.0 * std::sin(2.0 * M_PI * i / 1024.0)));
+        init = true;
+    }
+    return tab;
+}
+
+}  // namespace mi

@@ -1,0 +1,69 @@
+// plan.hpp -- host-side derived parameters of the hot path (everything the reference computes with
+// libm in double before its demod thread starts).  Device code afterwards needs only + - * / sqrt,
+// fma where the FFT spec says so, and compares.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/mi_airband.h"
+
+namespace mi {
+
+constexpr int kWaveRate = MI_WAVE_RATE;
+constexpr int kWaveBatch = MI_WAVE_BATCH;
+constexpr int kAgcExtra = MI_AGC_EXTRA;
+constexpr int kMaxTones = 52;
+constexpr int kSquelchRing = 102;  // Squelch::buffer_size_, squelch.cpp:67
+
+// Per-channel constants, identical for every stream of a handle.  Plain 4-byte fields: the struct is
+// copied verbatim into device memory.
+struct ChanParams {
+    uint32_t bin;
+    uint32_t dm_dphi;
+    int32_t modulation;
+    int32_t needs_raw_iq;
+    int32_t has_iq_outputs;
+    int32_t iq_row;  // row of this channel in the complex-bin plane, -1 if !needs_raw_iq
+    int32_t using_manual_level;
+    float manual_signal_level;
+    float normal_signal_ratio;
+    float flappy_signal_ratio;
+    float cap_factor;  // 1.5f * normal_signal_ratio (squelch.cpp:497 evaluates left to right)
+    float manual_cap;  // 1.5f * manual_signal_level
+    float ampfactor;
+    float alpha;
+    float one_minus_alpha;
+    int32_t notch_enabled;
+    float notch_d0, notch_d1, notch_d2;
+    int32_t lowpass_enabled;
+    float lowpass_gain, lowpass_yc0, lowpass_yc1;
+    int32_t ctcss_enabled;
+    int32_t ctcss_fast_window, ctcss_slow_window;
+    int32_t ctcss_fast_ndet, ctcss_slow_ndet;
+    int32_t ctcss_row;  // row in the detector coefficient/state tables, -1 if none
+};
+
+struct Plan {
+    mi_device_cfg dev{};
+    std::vector<mi_channel_cfg> chans;
+    int nch = 0;
+    int log2n = 0;
+    int fft_size = 0;
+    int bytes_per_sample = 1;
+    size_t hop_bytes = 0;  // "bps", rtl_airband.cpp:416
+    int n_iq_rows = 0;     // channels with needs_raw_iq
+    int n_ctcss_rows = 0;
+    std::vector<float> window;        // fft_size
+    std::vector<float> tw;            // fft_size/2 x {re, im}
+    std::vector<float> levels;        // 256 (u8 or s8 LUT)
+    float sin_lut[257], cos_lut[257];
+    float conv_scale = 0.f;           // 1.0f / fullscale (s16, f32)
+    std::vector<ChanParams> cp;       // nch
+    std::vector<float> ctcss_coeff;   // n_ctcss_rows x 2 x kMaxTones  (fast, slow)
+    float initial_noise_floor = 5.0f;
+};
+
+// returns MI_OK or a negative mi_status; msg receives the reason
+int build_plan(const mi_device_cfg& dev, const mi_channel_cfg* chans, int nch, Plan& out, const char** msg);
+
+}  // namespace mi

@@ -1,0 +1,202 @@
+/*
+ * mi_airband.h -- C ABI of the MI355X-native channelizer/demodulator (libmi_airband.so).
+ *
+ * This is the drop-in boundary for ONE path of Boondock-Airband: the body of demodulate()
+ * (reference src/rtl_airband.cpp:308-694) -- sample conversion x window, sliding FFT, bin pick,
+ * and the per-channel squelch / AM / NFM / CTCSS / filter loop -- between the reference's two
+ * shared-memory contracts: the input_t byte ring upstream (src/input-common.h:39-57) and
+ * channel_t.{waveout, iq_out, axcindicate} + device_t.waveavail downstream
+ * (src/boondock_airband.h:243-297).  Plain pointers and sizes only; no C++ types, no exceptions,
+ * never exits the process.  Every function returns 0 on success or a negative mi_status;
+ * mi_last_error() gives the message (the reference's own convention for inputs is int 0/-1,
+ * src/input-common.cpp:56-131; its VideoCore FFT seam returns -1/-2/-3, src/rtl_airband.cpp:318-332).
+ *
+ * Precedent seam in the reference: gpu_fft_prepare/gpu_fft_execute/gpu_fft_release
+ * (src/hello_fft/gpu_fft.h:60-74) + samplefft() (src/boondock_airband.h:87-92).  This ABI replaces
+ * the whole batch body, not only the FFT, so nothing but u8 IQ goes down and audio comes up.
+ */
+#ifndef MI_AIRBAND_H
+#define MI_AIRBAND_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* build-time constants of the reference's NFM build (src/boondock_airband.h:64-75) */
+#define MI_WAVE_RATE 16000
+#define MI_WAVE_BATCH 2000
+#define MI_AGC_EXTRA 100
+
+typedef enum {
+    MI_OK = 0,
+    MI_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
+    MI_ERR_NO_DEVICE = -2,   /* HIP runtime or GPU missing: the product path never falls back to CPU */
+    MI_ERR_NOMEM = -3,       /* host or device allocation failed */
+    MI_ERR_HIP = -4,         /* a HIP call or kernel launch failed */
+    MI_ERR_UNSUPPORTED = -5  /* valid in the reference, not built yet (afc > 0) */
+} mi_status;
+
+enum { MI_MOD_AM = 0, MI_MOD_NFM = 1 };                                        /* enum modulations, boondock_airband.h:202-208 */
+enum { MI_SFMT_U8 = 1, MI_SFMT_S8 = 2, MI_SFMT_S16 = 3, MI_SFMT_F32 = 4 };     /* sample_format_t, input-common.h:31 */
+enum { MI_NO_SIGNAL = ' ', MI_SIGNAL = '*', MI_AFC_UP = '<', MI_AFC_DOWN = '>' }; /* enum status, boondock_airband.h:101 */
+
+/* The DSP-relevant subset of a `devices` entry (src/config.cpp:731-808). */
+typedef struct mi_device_cfg {
+    int sample_rate;  /* Hz, input_t.sample_rate */
+    int centerfreq;   /* Hz, input_t.centerfreq */
+    int fft_size_log; /* global fft_size = 1<<log, 8..13 (boondock_airband.h:80-82) */
+    int sfmt;         /* MI_SFMT_*, input_t.sfmt */
+    float fullscale;  /* input_t.fullscale (s16/f32 only) */
+    int tau;          /* device `tau` in us; <0: the global default 200 us (rtl_airband.cpp:87) */
+    int fm_quadri;    /* 0: FM_FAST_ATAN2; 1: FM_QUADRI_DEMOD (the -Q flag) */
+} mi_device_cfg;
+
+/* The DSP-relevant subset of a `channels` entry (src/config.cpp:312-729), multichannel mode. */
+typedef struct mi_channel_cfg {
+    int freq;                   /* Hz */
+    int modulation;             /* MI_MOD_* */
+    int squelch_threshold_dbfs; /* `squelch_threshold`: 0 = unset/auto, <0 manual level in dBFS */
+    int has_snr_threshold;      /* `squelch_snr_threshold` present */
+    float squelch_snr_db;       /*   its value; -1 keeps the default 9.54 dB */
+    float notch_freq;           /* `notch` Hz, 0 = none */
+    float notch_q;              /* `notch_q`, 0 = default 10 */
+    float ctcss_freq;           /* `ctcss` Hz, 0 = none */
+    int bandwidth;              /* `bandwidth` Hz, 0 = none; >0 enables derotation + low-pass at bandwidth/2 */
+    float ampfactor;            /* `ampfactor`, default 1 */
+    int tau;                    /* channel `tau` us, <0 inherit the device's */
+    int afc;                    /* `afc` 0..255; >0 returns MI_ERR_UNSUPPORTED for now */
+    int has_iq_outputs;         /* the channel has a rawfile output (config.cpp:162) */
+} mi_channel_cfg;
+
+/* What the reference's stats file / TUI / JSON status read through Squelch getters on freq_t
+ * (src/output.cpp:634-811, rtl_airband.cpp:654-665), mirrored back once per call. */
+typedef struct mi_channel_stats {
+    float noise_level;   /* Squelch::noise_level() */
+    float signal_level;  /* Squelch::signal_level() */
+    float squelch_level; /* Squelch::squelch_level(), evaluated without touching its cache */
+    float agcavgfast;    /* freq_t.agcavgfast */
+    uint64_t open_count, flappy_count, ctcss_count, no_ctcss_count;
+    uint64_t active_counter; /* freq_t.active_counter (batches with axcindicate != NO_SIGNAL) */
+    int32_t squelch_state;   /* Squelch::State of current_state_ */
+    int32_t signal_outside_filter;
+} mi_channel_stats;
+
+typedef struct mi_demod mi_demod; /* nstreams independent device streams x nch channels, state resident in HBM */
+
+const char* mi_last_error(void);
+/* number of visible GPUs (0 if none / no runtime) -- never initialises more than the HIP runtime */
+int mi_device_count(void);
+
+/* Replaces init_demod() + the per-thread setup at the top of demodulate() (rtl_airband.cpp:253-266,
+ * 338-373): builds window, level LUTs, twiddles, per-channel derived parameters exactly as the
+ * reference derives them on the host, allocates device memory for up to max_batches WAVE_BATCHes per
+ * call, and resets every channel to the reference's initial state (config.cpp:271-287,319-334).
+ * All nstreams streams share the channel plan (the reference's "several dongles, same config" case). */
+int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int nch, int nstreams, int max_batches, int gpu,
+                    mi_demod** out);
+void mi_demod_destroy(mi_demod* h);
+
+/* Ring accounting for the caller (rtl_airband.cpp:416-417, 691).  A call producing nbatches batches
+ * runs n_fft windows, hop_bytes apart, the last one fft_size samples long:
+ *   needed   = (n_fft-1)*hop_bytes + 2*bytes_per_sample*fft_size   contiguous bytes from the stream position
+ *   consumed = n_fft*hop_bytes                                     how far input_t.bufs advances
+ * n_fft = nbatches*WAVE_BATCH (+AGC_EXTRA on a handle's first call, as waveend starts at 0). */
+size_t mi_demod_bytes_needed(const mi_demod* h, int nbatches);
+size_t mi_demod_bytes_consumed(const mi_demod* h, int nbatches);
+size_t mi_demod_hop_bytes(const mi_demod* h);
+
+/* Host-buffer entry: the batch body of demodulate() for all streams of the handle.
+ *   iq[s]      -> first byte of stream s at its current position (mi_demod_bytes_needed() readable bytes)
+ *   waveout    [nstreams][nch][nbatches*WAVE_BATCH + AGC_EXTRA]: exactly channel_t.waveout after the
+ *              reference's loop -- [0, nbatches*WAVE_BATCH) is what the output thread emits
+ *              (output.cpp:945-950), the last AGC_EXTRA samples are the not-yet-final lookahead
+ *   iq_out     [nstreams][nch][nbatches*WAVE_BATCH][2] or NULL; rows of channels without iq outputs are untouched
+ *   axc        [nstreams][nch][nbatches] MI_NO_SIGNAL / MI_SIGNAL per batch (channel_t.axcindicate)
+ *   stats      [nstreams][nch] or NULL
+ * Synchronous: on return the outputs are complete (publish waveavail after this returns). */
+int mi_demod_process(mi_demod* h, const uint8_t* const* iq, int nbatches, float* waveout, float* iq_out, char* axc,
+                     mi_channel_stats* stats);
+
+/* Device-resident entry (capture already in HBM; used for bulk replay and by bench.py).
+ *   d_iq            device pointer, stream s starts at d_iq + s*stream_stride_bytes
+ *   d_waveout       device [nstreams][nch][nbatches*WAVE_BATCH] -- the emitted samples only; the
+ *                   AGC_EXTRA lookahead stays in the handle
+ *   d_iq_out        device [nstreams][nch][nbatches*WAVE_BATCH][2] or NULL
+ *   d_axc           device [nstreams][nch][nbatches]
+ *   hip_stream      hipStream_t to enqueue on (NULL = default stream); asynchronous */
+int mi_demod_process_device(mi_demod* h, const void* d_iq, size_t stream_stride_bytes, int nbatches, float* d_waveout,
+                            float* d_iq_out, char* d_axc, void* hip_stream);
+
+/* stats of the last completed call (synchronises the handle's stream) */
+int mi_demod_get_stats(mi_demod* h, mi_channel_stats* stats /* [nstreams][nch] */);
+
+/* Checkpoint / resume of the complete per-channel DSP state (the reference has none). */
+size_t mi_demod_state_size(const mi_demod* h);
+int mi_demod_get_state(mi_demod* h, void* buf, size_t len);
+int mi_demod_set_state(mi_demod* h, const void* buf, size_t len);
+
+/* Diagnostic view of stage 1's output as stage 2 left it after the last call (synchronises): the
+ * magnitude plane of (stream, ch), plane index 0 = the oldest carried sample; after a call of n steps
+ * indices [0, AGC_EXTRA) hold the carry for the next call.  iq may be NULL; it is only filled for
+ * channels that need raw I/Q. Used by the stage-1 parity tests (channel_t.wavein / iq_in). */
+int mi_demod_read_planes(mi_demod* h, int stream, int ch, int first, int count, float* mag, float* iq);
+
+/* Timing of the kernels of the last mi_demod_process_device() call on its stream, from HIP events
+ * recorded around each launch (ms; synchronises). */
+int mi_demod_last_kernel_ms(mi_demod* h, float* channelize_ms, float* demod_ms);
+
+/* ---- host-only views of the derived plan (no GPU needed; used by the CPU test-suite) ---- */
+typedef struct mi_plan mi_plan;
+typedef struct mi_channel_derived {
+    uint32_t bin;       /* dev->bins[i], config.cpp:669-670 */
+    uint32_t dm_dphi;   /* channel_t.dm_dphi, config.cpp:682-713 */
+    int32_t needs_raw_iq, has_iq_outputs, modulation;
+    int32_t using_manual_level;
+    float manual_signal_level, normal_signal_ratio, flappy_signal_ratio;
+    float ampfactor, alpha;
+    int32_t notch_enabled;
+    float notch_d[3];
+    int32_t lowpass_enabled;
+    float lowpass_gain, lowpass_ycoeffs[2];
+    int32_t ctcss_enabled, ctcss_fast_window, ctcss_slow_window, ctcss_fast_ndet, ctcss_slow_ndet;
+} mi_channel_derived;
+
+int mi_plan_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int nch, mi_plan** out);
+void mi_plan_destroy(mi_plan* p);
+int mi_plan_fft_size(const mi_plan* p);
+int mi_plan_window(const mi_plan* p, float* out /* fft_size */);
+int mi_plan_twiddles(const mi_plan* p, float* out /* fft_size/2 x {re,im} */);
+int mi_plan_levels(const mi_plan* p, float* out /* 256, the LUT of the device's sample format */);
+int mi_plan_sincos_lut(const mi_plan* p, float* sin_out /* 257 */, float* cos_out /* 257 */);
+int mi_plan_channel(const mi_plan* p, int ch, mi_channel_derived* out);
+int mi_plan_ctcss_coeffs(const mi_plan* p, int ch, int slow, float* out /* ndet */);
+
+/* ---- synthetic IQ: integer-only, counter-based, identical on host and device ---- */
+typedef struct mi_iqgen_carrier {
+    int32_t offset_hz;   /* carrier offset from centre */
+    int32_t kind;        /* 0 AM (1 kHz tone, 50 % depth); 1 NFM (1 kHz tone, 2.5 kHz dev); 2 NFM + 100 Hz CTCSS */
+    int32_t amp_q8;      /* amplitude in 1/256 LSB (12 LSB = 3072) */
+    int32_t gate_phase;  /* carrier is on while ((n / gate_samples) + gate_phase) is odd; gate_samples 0 = always on */
+} mi_iqgen_carrier;
+
+typedef struct mi_iqgen_cfg {
+    int32_t sample_rate;
+    uint64_t seed;
+    int32_t noise_q8_mul;  /* noise scale: 111 gives sigma = 2.0 LSB */
+    uint64_t gate_samples; /* on/off period in samples (sample_rate = 1 s) */
+    int32_t ncarriers;
+    mi_iqgen_carrier carriers[64];
+} mi_iqgen_cfg;
+
+/* u8 interleaved IQ for samples [first, first+count) of stream `stream_id` */
+int mi_iqgen_host(const mi_iqgen_cfg* cfg, uint32_t stream_id, uint64_t first, uint64_t count, uint8_t* out);
+int mi_iqgen_device(const mi_iqgen_cfg* cfg, uint32_t first_stream_id, uint32_t nstreams, size_t stream_stride_bytes, uint64_t first,
+                    uint64_t count, void* d_out, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_AIRBAND_H */

@@ -1,0 +1,206 @@
+"""GPU parity: the HIP path, called through the C ABI (libmi_airband.so), against the CPU oracle on the
+same seeded synthetic IQ.  The bar (BASELINE.json north_star): audio within 1e-4 RMS, squelch open/close
+decisions bit-exact.  Because the FFT arithmetic is specified operation by operation the HIP
+path reproduces the oracle exactly, so these tests assert equality of every float (== semantics, i.e. up
+to the sign of zero) and of every squelch flag -- strictly stronger than the stated tolerance, which is
+asserted as well."""
+import numpy as np
+import pytest
+
+from common import AGC_EXTRA, WAVE_BATCH, assert_same, bytes_for_batches, gen_iq, oracle_run, rms
+
+pytestmark = pytest.mark.gpu
+
+TOL_RMS = 1e-4  # north_star: audio output matches the CPU path within 1e-4 RMS
+
+
+def run_product_batches(pkg, dev, chans, iq, nbatches, per_call=1, want_iq=False, nstreams=1):
+    """Feed the host-buffer entry the way demodulate() consumes the ring: `per_call` batches per call."""
+    d = pkg.Demod(dev, chans, nstreams=nstreams, max_batches=per_call)
+    outs, flags, iqs = [], [], []
+    pos = 0
+    done = 0
+    while done < nbatches:
+        k = min(per_call, nbatches - done)
+        wo, axc, iqo, _ = d.process([iq[pos:]] * nstreams, k, want_iq=want_iq)
+        outs.append(wo[:, :, :k * WAVE_BATCH])
+        flags.append(axc)
+        if want_iq:
+            iqs.append(iqo)
+        done += k
+        # advance exactly like input_t.bufs (rtl_airband.cpp:691): hop bytes per window processed
+        pos = (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+    st = d.stats()
+    d.close()
+    return np.concatenate(outs, axis=2), np.concatenate(flags, axis=2), (np.concatenate(iqs, axis=2) if want_iq else None), st
+
+
+def check_against_oracle(pkg, dev, chans, iq, nbatches, per_call, want_iq=False):
+    nb, owo, oaxc, oiq = oracle_run(dev, chans, iq, nbatches, want_iq=want_iq)
+    assert nb == nbatches
+    wo, axc, iqo, st = run_product_batches(pkg, dev, chans, iq, nbatches, per_call=per_call, want_iq=want_iq)
+    assert_same(axc[0], oaxc, "axcindicate per batch")
+    # squelch decisions per sample: closed samples are exactly 0 in both
+    assert_same(wo[0] != 0, owo != 0, "per-sample squelch mask")
+    for c in range(len(chans)):
+        assert rms(wo[0, c] - owo[c]) <= TOL_RMS
+    assert_same(wo[0], owo, "audio")
+    if want_iq:
+        for c, ch in enumerate(chans):
+            if ch.has_iq_outputs:
+                assert_same(iqo[0, c].reshape(-1), oiq[c], f"iq_out ch{c}")
+    return wo, axc, st
+
+
+def test_config2_batch_by_batch(pkg):
+    """BASELINE configs[1]: 1 stream, 8 AM channels, fft 512; one WAVE_BATCH per call like the reference loop."""
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    iq, _ = gen_iq(pkg, dev, centre, chans, 16)
+    wo, axc, st = check_against_oracle(pkg, dev, chans, iq, 16, per_call=1)
+    assert (axc[0, 0] == ord("*")).any() and (axc[0, 1] == ord(" ")).all()
+    assert st[0].open_count >= 2
+
+
+def test_config2_bulk_equals_streaming(pkg):
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    iq, _ = gen_iq(pkg, dev, centre, chans, 16)
+    check_against_oracle(pkg, dev, chans, iq, 16, per_call=16)
+    check_against_oracle(pkg, dev, chans, iq, 16, per_call=5)
+
+
+def test_config3_mixed_am_nfm_ctcss(pkg):
+    """BASELINE configs[2]: 32 channels AM+NFM(+CTCSS, notch), fft 2048."""
+    centre, chans = pkg.config3_channels()
+    chans[3].has_iq_outputs = 1
+    chans[4].has_iq_outputs = 1
+    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=11)
+    iq, _ = gen_iq(pkg, dev, centre, chans, 12, gate_div=2, active=lambda k: k % 4 != 2)
+    wo, axc, st = check_against_oracle(pkg, dev, chans, iq, 12, per_call=4, want_iq=True)
+    nfm_open = [(axc[0, k] == ord("*")).any() for k in range(32) if k % 2 == 1]
+    assert any(nfm_open)
+
+
+@pytest.mark.parametrize("log2n", [8, 10, 12, 13])
+def test_other_fft_sizes(pkg, log2n):
+    centre = 120000000
+    chans = [pkg.channel_cfg(centre + 300000), pkg.channel_cfg(centre - 450000, modulation=pkg.MOD_NFM),
+             pkg.channel_cfg(centre + 777000, squelch_snr_db=6.0)]
+    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=log2n)
+    iq, _ = gen_iq(pkg, dev, centre, chans, 6, gate_div=4, active=lambda k: True)
+    check_against_oracle(pkg, dev, chans, iq, 6, per_call=2)
+
+
+def test_manual_squelch_and_options(pkg):
+    centre = 120000000
+    chans = [pkg.channel_cfg(centre + 250000, squelch_threshold_dbfs=-40),
+             pkg.channel_cfg(centre - 250000, squelch_snr_db=0.0, ampfactor=2.5),
+             pkg.channel_cfg(centre + 500000, modulation=pkg.MOD_NFM, tau=0, notch=1000.0, notch_q=5.0),
+             pkg.channel_cfg(centre - 500000, bandwidth=8000, has_iq_outputs=1),
+             pkg.channel_cfg(centre + 750000, modulation=pkg.MOD_NFM, ctcss=100.0, bandwidth=12500)]
+    dev = pkg.device_cfg(centerfreq=centre, tau=75)
+    iq, _ = gen_iq(pkg, dev, centre, chans, 10, gate_div=2, active=lambda k: True)
+    check_against_oracle(pkg, dev, chans, iq, 10, per_call=3, want_iq=True)
+    dev_q = pkg.device_cfg(centerfreq=centre, fm_quadri=1)
+    check_against_oracle(pkg, dev_q, chans, iq, 10, per_call=10, want_iq=True)
+
+
+def test_multi_stream_independent(pkg):
+    """Streams of one handle are independent devices: stream s must equal a single-stream run on its IQ."""
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    ns, nbat = 3, 6
+    iqs = [gen_iq(pkg, dev, centre, chans, nbat, stream=s, gate_div=3 + s)[0] for s in range(ns)]
+    d = pkg.Demod(dev, chans, nstreams=ns, max_batches=nbat)
+    wo, axc, _, _ = d.process(iqs, nbat)
+    d.close()
+    for s in range(ns):
+        nb, owo, oaxc, _ = oracle_run(dev, chans, iqs[s], nbat)
+        assert nb == nbat
+        assert_same(wo[s, :, :nbat * WAVE_BATCH], owo, f"stream {s} audio")
+        assert_same(axc[s], oaxc, f"stream {s} flags")
+
+
+def test_device_entry_and_iqgen(pkg):
+    """Device-resident path with IQ generated on the GPU: bytes equal the host generator, audio equals the oracle."""
+    import torch
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    nbat = 8
+    iq, cfg = gen_iq(pkg, dev, centre, chans, nbat)
+    nbytes = (iq.size + 255) // 256 * 256
+    d_iq = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    pkg.iqgen_device(cfg, 0, 1, nbytes, 0, iq.size // 2, d_iq.data_ptr())
+    torch.cuda.synchronize()
+    assert_same(d_iq.cpu().numpy()[:iq.size], iq, "device-generated IQ bytes")
+    d = pkg.Demod(dev, chans, nstreams=1, max_batches=nbat)
+    d_wo = torch.zeros((1, len(chans), nbat * WAVE_BATCH), dtype=torch.float32, device="cuda")
+    d_axc = torch.zeros((1, len(chans), nbat), dtype=torch.uint8, device="cuda")
+    d.process_device(d_iq.data_ptr(), nbytes, nbat, d_wo.data_ptr(), d_axc.data_ptr(), hip_stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    nb, owo, oaxc, _ = oracle_run(dev, chans, iq, nbat)
+    assert_same(d_wo.cpu().numpy()[0], owo, "audio (device entry)")
+    assert_same(d_axc.cpu().numpy()[0], oaxc, "flags (device entry)")
+    k1, k2 = d.last_kernel_ms()
+    assert k1 > 0 and k2 > 0
+    d.close()
+
+
+def test_checkpoint_resume(pkg):
+    centre, chans = pkg.config3_channels()
+    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=11)
+    iq, _ = gen_iq(pkg, dev, centre, chans, 8, gate_div=2, active=lambda k: k % 4 != 2)
+    a = pkg.Demod(dev, chans, max_batches=4)
+    wo1, axc1, _, _ = a.process([iq], 4)
+    blob = a.get_state()
+    pos = (4 * WAVE_BATCH + AGC_EXTRA) * a.hop_bytes
+    wo2, axc2, _, _ = a.process([iq[pos:]], 4)
+    a.close()
+    b = pkg.Demod(dev, chans, max_batches=4)
+    b.set_state(blob)
+    wo3, axc3, _, _ = b.process([iq[pos:]], 4)
+    b.close()
+    assert_same(wo3, wo2, "audio after resume")
+    assert_same(axc3, axc2, "flags after resume")
+
+
+@pytest.mark.parametrize("sfmt", ["s8", "s16", "f32"])
+def test_other_sample_formats(pkg, sfmt):
+    """the s8 / s16 / f32 convert variants (rtl_airband.cpp:424-477)."""
+    centre, chans = pkg.config2_channels()
+    base = pkg.device_cfg(centerfreq=centre)
+    iq, _ = gen_iq(pkg, base, centre, chans, 4)
+    if sfmt == "s8":
+        dev = pkg.device_cfg(centerfreq=centre, sfmt=pkg.SFMT_S8)
+        raw = (iq.astype(np.int16) - 128).astype(np.int8).view(np.uint8)
+    elif sfmt == "s16":
+        dev = pkg.device_cfg(centerfreq=centre, sfmt=pkg.SFMT_S16, fullscale=32767.5)
+        raw = ((iq.astype(np.int32) - 128) * 256 + 37).astype(np.int16).view(np.uint8)
+    else:
+        dev = pkg.device_cfg(centerfreq=centre, sfmt=pkg.SFMT_F32, fullscale=1.0)
+        raw = ((iq.astype(np.float32) - 127.5) / 127.5).astype(np.float32).view(np.uint8)
+    nb, owo, oaxc, _ = oracle_run(dev, chans, raw, 4)
+    assert nb == 4
+    d = pkg.Demod(dev, chans, max_batches=4)
+    wo, axc, _, _ = d.process([raw], 4)
+    d.close()
+    assert_same(wo[0, :, :4 * WAVE_BATCH], owo, f"audio {sfmt}")
+    assert_same(axc[0], oaxc, f"flags {sfmt}")
+
+
+def test_error_paths(pkg):
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    with pytest.raises(pkg.MiError) as e:
+        pkg.Demod(pkg.device_cfg(fft_size_log=7), chans)
+    assert e.value.code == pkg.MI_ERR_INVALID
+    bad = list(chans)
+    bad[0] = pkg.channel_cfg(chans[0].freq, afc=2)
+    with pytest.raises(pkg.MiError) as e:
+        pkg.Demod(dev, bad)
+    assert e.value.code == pkg.MI_ERR_UNSUPPORTED
+    d = pkg.Demod(dev, chans, max_batches=2)
+    with pytest.raises(pkg.MiError):
+        d.process([np.zeros(d.bytes_needed(3), np.uint8)], 3)  # more than max_batches
+    d.close()
