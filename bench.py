@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the demodulate() hot path on MI355X (BASELINE.json metric).
+
+Workload (config.workload): BASELINE configs[1] -- per GPU ONE device stream of synthetic 2.56 MS/s u8 IQ,
+8 AM channels, fft_size 512 (SURVEY 8d channel plan and signal recipe).  A "step" is one pass of the whole
+path (channelize kernel + demod kernel, through the C ABI's device-resident entry) over `--seconds` of
+capture already resident in HBM.  With N GPUs each rank owns its own stream (independent dongles, weak
+scaling) and the decimated audio of every rank is gathered to rank 0 over RCCL inside the timed region.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is for the kernel that dominates the step, from HIP events the
+library records on its launch stream around each kernel; `cpu_baseline` is the CPU oracle (a port of the
+reference path, oracle/airband_oracle.c) timed on one host core over a bounded sample of the same workload.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+SAMPLE_RATE = 2560000
+WAVE_BATCH = 2000
+AGC_EXTRA = 100
+
+
+def load_package():
+    name = "boondock_airband_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(ROOT, "boondock-airband_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=[os.path.dirname(path)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_baseline(pkg, dev, centre, chans, seconds):
+    """The oracle (port of the reference's CPU path) on one host core, free-running from memory."""
+    from common import gen_iq, oracle_run
+    nbat = int(seconds * 8)
+    iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=1)
+    t0 = time.perf_counter()
+    nb, _, _, _ = oracle_run(dev, chans, iq, nbat)
+    dt = time.perf_counter() - t0
+    samples = nb * WAVE_BATCH * (SAMPLE_RATE // 16000)
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": samples / dt / 1e6, "unit": "MS/s", "cores": 1, "kind": "port",
+            "sample": f"{nb} WAVE_BATCHes ({nb / 8:.1f} s of the same 1-stream 8-AM-channel fft512 capture), oracle/airband_oracle.c "
+                      f"(own radix-2 FFT, FFTW3f absent), 1 thread = the reference's one-demod-thread-per-device model; host CPU: {model}",
+            "x_realtime": samples / dt / SAMPLE_RATE}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=8.0, help="capture length per stream per step (HBM-resident)")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="length of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of audio to rank 0 (N>1)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    pkg = load_package()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=9)
+    nch = len(chans)
+    nbat = max(1, int(round(args.seconds * 8)))
+    nsteps = nbat * WAVE_BATCH
+    hop = 2 * (SAMPLE_RATE // 16000)
+    nbytes = ((nsteps + AGC_EXTRA) * hop + 2 * 512 + 255) // 256 * 256
+    stream = torch.cuda.current_stream()
+
+    # synthetic capture of this rank's stream, generated on the device (same integer recipe as the host generator)
+    gcfg = pkg.iqgen_cfg(sample_rate=SAMPLE_RATE, gate_samples=SAMPLE_RATE, carriers=pkg.carriers_for(centre, chans))
+    d_iq = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    pkg.iqgen_device(gcfg, rank, 1, nbytes, 0, nbytes // 2, d_iq.data_ptr(), stream.cuda_stream)
+    d_wo = torch.empty((1, nch, nsteps), dtype=torch.float32, device="cuda")
+    d_axc = torch.empty((1, nch, nbat), dtype=torch.uint8, device="cuda")
+    gather_list = None
+    if world > 1 and not args.no_gather and rank == 0:
+        gather_list = [torch.empty_like(d_wo) for _ in range(world)]
+
+    h = pkg.Demod(dev, chans, nstreams=1, max_batches=nbat, gpu=local_rank)
+    # prime: the handle's first call consumes AGC_EXTRA extra windows (waveend starts at 0 in the reference)
+    h.process_device(d_iq.data_ptr(), nbytes, nbat, d_wo.data_ptr(), d_axc.data_ptr(), hip_stream=stream.cuda_stream)
+    base = d_iq.data_ptr() + AGC_EXTRA * hop
+    kms = [0.0, 0.0]
+
+    def step(timed):
+        h.process_device(base, nbytes - AGC_EXTRA * hop, nbat, d_wo.data_ptr(), d_axc.data_ptr(), hip_stream=stream.cuda_stream)
+        if world > 1 and not args.no_gather:
+            dist.gather(d_wo, gather_list, dst=0)
+        if timed:
+            a, b = h.last_kernel_ms()  # HIP events around each kernel on the launch stream
+            kms[0] += a
+            kms[1] += b
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    samples_per_step_per_gpu = nsteps * (SAMPLE_RATE // 16000)
+    total_samples = samples_per_step_per_gpu * args.steps * world
+    value = total_samples / dt / 1e6  # MS/s, whole job
+
+    if rank == 0:
+        ch_ms, dm_ms = kms[0] / args.steps, kms[1] / args.steps
+        # algorithmic HBM bytes per complex input sample (DESIGN.md "Kernels"):
+        #   channelize: 2 B IQ read + 4*nch/160 B magnitudes written           (2.2 B/sample @ 8 ch)
+        #   demod     : 4*nch/160 B magnitudes read + 4*nch/160 B audio written
+        hopn = SAMPLE_RATE // 16000
+        bytes_ch = samples_per_step_per_gpu * (2.0 + 4.0 * nch / hopn)
+        bytes_dm = samples_per_step_per_gpu * (8.0 * nch / hopn)
+        kernels = {
+            "channelize": {"ms": ch_ms, "algorithmic_bytes": bytes_ch, "GBps": bytes_ch / (ch_ms * 1e-3) / 1e9 if ch_ms > 0 else None},
+            "demod": {"ms": dm_ms, "algorithmic_bytes": bytes_dm, "GBps": bytes_dm / (dm_ms * 1e-3) / 1e9 if dm_ms > 0 else None},
+        }
+        dom = "channelize" if ch_ms >= dm_ms else "demod"
+        achieved = kernels[dom]["GBps"]
+        out = {
+            "metric": "IQ MS/s processed (x real-time) @ 8ch fft_size=512",
+            "value": value,
+            "unit": "MS/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 1 device stream per GPU @ 2.56 MS/s u8 IQ, 8 AM channels, fft_size=512",
+                       "streams_per_gpu": 1, "channels": nch, "fft_size": 512, "capture_seconds_per_step": nbat / 8.0,
+                       "audio_gather_to_rank0": bool(world > 1 and not args.no_gather)},
+            "x_realtime_per_stream": value / world / (SAMPLE_RATE / 1e6),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None},
+            "kernels": kernels,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(pkg, dev, centre, chans, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -117,3 +117,75 @@ int ao_ctcss_detector_count(float freq, float rate, int window) {
 size_t ao_sizeof_demod_channel(void) {
     return sizeof(ao_channel);
 }
+
+/* ---- views of derived parameters, laid out like mi_channel_derived (include/mi_airband.h) so the
+ * product's host-side plan can be compared field by field ---- */
+typedef struct {
+    uint32_t bin, dm_dphi;
+    int32_t needs_raw_iq, has_iq_outputs, modulation, using_manual_level;
+    float manual_signal_level, normal_signal_ratio, flappy_signal_ratio, ampfactor, alpha;
+    int32_t notch_enabled;
+    float notch_d[3];
+    int32_t lowpass_enabled;
+    float lowpass_gain, lowpass_ycoeffs[2];
+    int32_t ctcss_enabled, ctcss_fast_window, ctcss_slow_window, ctcss_fast_ndet, ctcss_slow_ndet;
+} ao_channel_derived;
+
+void ao_demod_channel_derived(const ao_demod* d, int i, ao_channel_derived* o) {
+    const ao_channel* c = &d->ch[i];
+    memset(o, 0, sizeof(*o));
+    o->bin = (uint32_t)c->bin;
+    o->dm_dphi = c->dm_dphi;
+    o->needs_raw_iq = c->needs_raw_iq;
+    o->has_iq_outputs = c->has_iq_outputs;
+    o->modulation = c->modulation;
+    o->using_manual_level = c->squelch.using_manual_level;
+    o->manual_signal_level = c->squelch.manual_signal_level;
+    o->normal_signal_ratio = c->squelch.normal_signal_ratio;
+    o->flappy_signal_ratio = c->squelch.flappy_signal_ratio;
+    o->ampfactor = c->ampfactor;
+    o->alpha = c->alpha;
+    o->notch_enabled = c->notch.enabled;
+    memcpy(o->notch_d, c->notch.d, sizeof(o->notch_d));
+    o->lowpass_enabled = c->lowpass.enabled;
+    o->lowpass_gain = c->lowpass.gain;
+    o->lowpass_ycoeffs[0] = c->lowpass.ycoeffs[0];
+    o->lowpass_ycoeffs[1] = c->lowpass.ycoeffs[1];
+    o->ctcss_enabled = c->squelch.ctcss_slow.enabled;
+    o->ctcss_fast_window = c->squelch.ctcss_fast.window_size;
+    o->ctcss_slow_window = c->squelch.ctcss_slow.window_size;
+    o->ctcss_fast_ndet = c->squelch.ctcss_fast.ndet;
+    o->ctcss_slow_ndet = c->squelch.ctcss_slow.ndet;
+}
+
+void ao_demod_ctcss_coeffs(const ao_demod* d, int i, int slow, float* out) {
+    const ao_ctcss* c = slow ? &d->ch[i].squelch.ctcss_slow : &d->ch[i].squelch.ctcss_fast;
+    memcpy(out, c->det_coeff, sizeof(float) * (size_t)c->ndet);
+}
+
+void ao_demod_tables(const ao_demod* d, float* window, float* tw_re_im, float* levels, float* sin_lut, float* cos_lut) {
+    memcpy(window, d->window, sizeof(float) * d->fft_size);
+    for (size_t k = 0; k < d->fft_size / 2; k++) {
+        tw_re_im[2 * k] = d->plan.tw_re[k];
+        tw_re_im[2 * k + 1] = d->plan.tw_im[k];
+    }
+    memcpy(levels, d->cfg.sfmt == AO_SFMT_S8 ? d->levels_s8 : d->levels_u8, sizeof(float) * 256);
+    memcpy(sin_lut, d->sin_lut, sizeof(float) * 257);
+    memcpy(cos_lut, d->cos_lut, sizeof(float) * 257);
+}
+
+/* forward FFT of one interleaved complex vector (for the DFT-definition check) */
+void ao_fft_run(int log2n, const float* in, float* out) {
+    ao_fft_plan p;
+    if (ao_fft_plan_init(&p, log2n) != 0)
+        return;
+    ao_fft_forward(&p, in, out);
+    ao_fft_plan_free(&p);
+}
+
+/* squelch state snapshot after feeding raw samples only (for the reference's behavioural unit tests) */
+typedef struct {
+    float noise_level, squelch_level;
+    int32_t is_open, should_process_audio;
+    uint64_t open_count, ctcss_count, no_ctcss_count;
+} ao_squelch_probe;

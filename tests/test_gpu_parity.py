@@ -76,7 +76,7 @@ def test_config3_mixed_am_nfm_ctcss(pkg):
     chans[3].has_iq_outputs = 1
     chans[4].has_iq_outputs = 1
     dev = pkg.device_cfg(centerfreq=centre, fft_size_log=11)
-    iq, _ = gen_iq(pkg, dev, centre, chans, 12, gate_div=2, active=lambda k: k % 4 != 2)
+    iq, _ = gen_iq(pkg, dev, centre, chans, 12, gate_div=2, active=lambda k: k % 4 != 2, amp_q8=1024)
     wo, axc, st = check_against_oracle(pkg, dev, chans, iq, 12, per_call=4, want_iq=True)
     nfm_open = [(axc[0, k] == ord("*")).any() for k in range(32) if k % 2 == 1]
     assert any(nfm_open)
@@ -150,7 +150,7 @@ def test_device_entry_and_iqgen(pkg):
 def test_checkpoint_resume(pkg):
     centre, chans = pkg.config3_channels()
     dev = pkg.device_cfg(centerfreq=centre, fft_size_log=11)
-    iq, _ = gen_iq(pkg, dev, centre, chans, 8, gate_div=2, active=lambda k: k % 4 != 2)
+    iq, _ = gen_iq(pkg, dev, centre, chans, 8, gate_div=2, active=lambda k: k % 4 != 2, amp_q8=1024)
     a = pkg.Demod(dev, chans, max_batches=4)
     wo1, axc1, _, _ = a.process([iq], 4)
     blob = a.get_state()
