@@ -79,7 +79,7 @@ class IqGenCfg(C.Structure):
 ABI_SYMBOLS = [
     "mi_last_error", "mi_device_count", "mi_demod_create", "mi_demod_destroy", "mi_demod_bytes_needed", "mi_demod_bytes_consumed",
     "mi_demod_hop_bytes", "mi_demod_process", "mi_demod_process_device", "mi_demod_get_stats", "mi_demod_state_size",
-    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
+    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
     "mi_plan_window", "mi_plan_twiddles", "mi_plan_levels", "mi_plan_sincos_lut", "mi_plan_channel", "mi_plan_ctcss_coeffs",
     "mi_iqgen_host", "mi_iqgen_device",
 ]
@@ -112,6 +112,7 @@ def lib():
         L.mi_demod_state_size.restype = sz
         L.mi_demod_get_state.argtypes = [vp, vp, sz]
         L.mi_demod_set_state.argtypes = [vp, vp, sz]
+        L.mi_demod_last_path.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mi_demod_read_planes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.mi_demod_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mi_plan_create.argtypes = [C.POINTER(DeviceCfg), C.POINTER(ChannelCfg), C.c_int, C.POINTER(vp)]
@@ -262,6 +263,12 @@ class Demod:
     def set_state(self, buf):
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         _check(lib().mi_demod_set_state(self._h, buf.ctypes.data_as(C.c_void_p), buf.size))
+
+    def last_path(self):
+        """(1 if the last call ran the time-parallel stage 2 else 0, rows left unverified -- always 0)."""
+        a, b = C.c_int(0), C.c_int(0)
+        _check(lib().mi_demod_last_path(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def read_planes(self, stream, ch, first, count, want_iq=False):
         mag = np.zeros(count, np.float32)

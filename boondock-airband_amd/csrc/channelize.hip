@@ -270,6 +270,14 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
         if (i < nw)
             a.mag[(static_cast<size_t>(stream) * a.nch + c) * a.plane_stride + a.plane_off + w0 + i] = out_mag[idx];
     }
+    if (a.xmax) {  // upper bound the time-parallel stage 2 starts its sandwich from
+        for (int c = tid; c < a.nch; c += BLOCK) {
+            float m = 0.0f;
+            for (int i = 0; i < nw; ++i)
+                m = fmaxf(m, out_mag[c * TW + i]);
+            atomicMax(a.xmax + static_cast<size_t>(stream) * a.nch + c, __float_as_uint(m));
+        }
+    }
     for (int idx = tid; idx < a.n_iq_rows * TW; idx += BLOCK) {
         const int c = idx / TW, i = idx - c * TW;
         if (i < nw)

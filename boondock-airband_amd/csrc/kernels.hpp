@@ -57,6 +57,7 @@ struct ChannelizeArgs {
     float conv_scale;
     const ChanParams* cp;
     int nch, n_iq_rows;
+    unsigned* xmax;  // [nstreams*nch] running max of the magnitudes written (bit pattern; values are >= 0), or null
 };
 
 struct DemodArgs {
@@ -83,6 +84,52 @@ struct DemodArgs {
     int fm_quadri;
     int lanes_per_wave;
 };
+
+// ---- time-parallel stage 2 (tp.hip) ----
+constexpr uint32_t TP_L = 512;      // steps per segment
+constexpr uint32_t TP_W = 4096;     // warm-up of the state machine / AGC before a segment (multiple of TP_L)
+constexpr uint32_t TP_L1 = 512;     // steps per lane of the full_ sandwich pass
+constexpr uint32_t TP_W1 = 4096;    // its warm-up
+constexpr int TP_MAXEV = 4;         // close-edge fades per segment (they are >= 197 steps apart: at most 3)
+constexpr uint32_t TP_MAXCHAIN = 32;
+constexpr int TP_NREC = 19 + TP_MAXEV;
+
+struct TpCore {
+    float nf, cap, c, full;
+};
+struct TpFinal {
+    int cur, next, delay, low, recent, closed;
+    float agc;
+    int all_ok;
+    uint32_t first_bad;
+    int d_open, d_flappy;
+    int pad;
+};
+
+struct TpArgs {
+    const int* rows;  // handle rows (stream*nch + ch) taking this path
+    int nrows, nch;
+    uint32_t nsteps, nbatches, nblk, nseg;
+    float* mag;
+    size_t plane_stride;
+    float* wmain;
+    size_t wmain_stride;
+    float* carry;
+    char* axc;
+    const ChanParams* cp;
+    ChanState* st;
+    mi_channel_stats* stats;
+    const unsigned* xmax;  // [handle rows] bit pattern of the largest magnitude stage 1 wrote this call
+    float *blk_fe, *blk_fm, *blk_x0, *blk_xm;  // [nrows][nblk]
+    TpCore* core;                              // [nrows][nseg+1]
+    int* rec;                                  // [TP_NREC][rec_stride]
+    size_t rec_stride;
+    int* tstart;                               // [nrows*nseg][8]
+    int* need;                                 // [nrows*nseg]
+    TpFinal* fin;                              // [nrows]
+};
+
+hipError_t launch_tp(const TpArgs& a, hipStream_t s);
 
 hipError_t launch_channelize(const ChannelizeArgs& a, int log2n, int sfmt, int nstreams, hipStream_t s);
 hipError_t launch_demod(const DemodArgs& a, hipStream_t s);

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -81,6 +82,18 @@ struct mi_demod {
     char* d_axc = nullptr;
     unsigned char* h_pin = nullptr;  // pinned bounce buffer for the IQ upload
     size_t h_pin_bytes = 0;
+    // time-parallel stage 2 (tp.hip): only when every channel is a plain AM channel
+    bool tp_eligible = false;
+    int last_path = 0;  // 0 = serial kernel, 1 = time-parallel
+    int* d_rows = nullptr;
+    unsigned* d_xmax = nullptr;
+    float *d_blk_fe = nullptr, *d_blk_fm = nullptr, *d_blk_x0 = nullptr, *d_blk_xm = nullptr;
+    mi::TpCore* d_core = nullptr;
+    int* d_rec = nullptr;
+    int* d_tstart = nullptr;
+    int* d_need = nullptr;
+    mi::TpFinal* d_fin = nullptr;
+    size_t tp_max_blk = 0, tp_max_seg = 0;
 };
 
 namespace {
@@ -88,6 +101,15 @@ namespace {
 int n_fft_for(const mi_demod* h, int nbatches) {
     return nbatches * mi::kWaveBatch + (h->first_call ? mi::kAgcExtra : 0);
 }
+
+// MI_AIRBAND_TP=0 forces the serial kernel, =1 forces the time-parallel path whenever it is eligible
+int tp_env() {
+    const char* e = std::getenv("MI_AIRBAND_TP");
+    if (!e || !*e)
+        return -1;
+    return std::atoi(e) != 0 ? 1 : 0;
+}
+constexpr int kTpMinBatches = 8;  // below this the segments are too few to pay for the extra passes
 
 int lanes_per_wave_for(int rows) {
     // up to 1024 waves (4 per CU) keep one channel each; beyond that pack lanes
@@ -120,6 +142,9 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     ca.cp = h->d_cp;
     ca.nch = h->nch;
     ca.n_iq_rows = h->plan.n_iq_rows;
+    const int env = tp_env();
+    const bool use_tp = h->tp_eligible && env != 0 && (env == 1 || nbatches >= kTpMinBatches);
+    ca.xmax = use_tp ? h->d_xmax : nullptr;
 
     mi::DemodArgs da{};
     da.nstreams = h->nstreams;
@@ -148,10 +173,45 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     da.fm_quadri = h->plan.dev.fm_quadri;
     da.lanes_per_wave = lanes_per_wave_for(h->rows);
 
+    if (use_tp)
+        HIP_TRY(hipMemsetAsync(h->d_xmax, 0, static_cast<size_t>(h->rows) * sizeof(unsigned), s));
     HIP_TRY(hipEventRecord(h->ev[0], s));
     HIP_TRY(mi::launch_channelize(ca, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, s));
     HIP_TRY(hipEventRecord(h->ev[1], s));
-    HIP_TRY(mi::launch_demod(da, s));
+    if (use_tp) {
+        mi::TpArgs ta{};
+        ta.rows = h->d_rows;
+        ta.nrows = h->rows;
+        ta.nch = h->nch;
+        ta.nsteps = da.nsteps;
+        ta.nbatches = da.nbatches;
+        ta.nblk = da.nsteps / 16;
+        ta.nseg = (da.nsteps + mi::TP_L - 1) / mi::TP_L;
+        ta.mag = h->d_mag;
+        ta.plane_stride = h->plane_stride;
+        ta.wmain = d_wmain;
+        ta.wmain_stride = wmain_stride;
+        ta.carry = h->d_carry;
+        ta.axc = d_axc;
+        ta.cp = h->d_cp;
+        ta.st = h->d_state;
+        ta.stats = h->d_stats;
+        ta.xmax = h->d_xmax;
+        ta.blk_fe = h->d_blk_fe;
+        ta.blk_fm = h->d_blk_fm;
+        ta.blk_x0 = h->d_blk_x0;
+        ta.blk_xm = h->d_blk_xm;
+        ta.core = h->d_core;
+        ta.rec = h->d_rec;
+        ta.rec_stride = static_cast<size_t>(h->rows) * h->tp_max_seg;
+        ta.tstart = h->d_tstart;
+        ta.need = h->d_need;
+        ta.fin = h->d_fin;
+        HIP_TRY(mi::launch_tp(ta, s));
+    } else {
+        HIP_TRY(mi::launch_demod(da, s));
+    }
+    h->last_path = use_tp ? 1 : 0;
     HIP_TRY(hipEventRecord(h->ev[2], s));
     h->ev_valid = true;
     h->first_call = false;
@@ -178,7 +238,8 @@ void mi_demod_destroy(mi_demod* h) {
         return;
     (void)hipSetDevice(h->gpu);
     void* ptrs[] = {h->d_window, h->d_tw,   h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_mag,   h->d_cplx, h->d_carry,
-                    h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc};
+                    h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc,
+                    h->d_rows,   h->d_xmax, h->d_blk_fe, h->d_blk_fm, h->d_blk_x0, h->d_blk_xm, h->d_core, h->d_rec, h->d_tstart, h->d_need, h->d_fin};
     for (void* p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -272,6 +333,30 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     if (h->d_cplx)
         TRY_OR_BAIL(hipMemset(h->d_cplx, 0, static_cast<size_t>(nstreams) * p.n_iq_rows * h->plane_stride * 8));
     TRY_OR_BAIL(hipMemset(h->d_stats, 0, rows * sizeof(mi_channel_stats)));
+    h->tp_eligible = true;
+    for (const mi::ChanParams& c : p.cp)
+        if (c.modulation != MI_MOD_AM || c.needs_raw_iq || c.ctcss_enabled || c.notch_enabled)
+            h->tp_eligible = false;
+    if (h->tp_eligible) {
+        h->tp_max_blk = max_steps / 16;
+        h->tp_max_seg = (max_steps + mi::TP_L - 1) / mi::TP_L;
+        std::vector<int> ident(rows);
+        for (size_t i = 0; i < rows; ++i)
+            ident[i] = static_cast<int>(i);
+        TRY_OR_BAIL(dalloc(&h->d_rows, rows));
+        TRY_OR_BAIL(hipMemcpy(h->d_rows, ident.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+        TRY_OR_BAIL(dalloc(&h->d_xmax, rows));
+        TRY_OR_BAIL(dalloc(&h->d_blk_fe, rows * h->tp_max_blk));
+        TRY_OR_BAIL(dalloc(&h->d_blk_fm, rows * h->tp_max_blk));
+        TRY_OR_BAIL(dalloc(&h->d_blk_x0, rows * h->tp_max_blk));
+        TRY_OR_BAIL(dalloc(&h->d_blk_xm, rows * h->tp_max_blk));
+        TRY_OR_BAIL(dalloc(&h->d_core, rows * (h->tp_max_seg + 1)));
+        TRY_OR_BAIL(dalloc(&h->d_rec, static_cast<size_t>(mi::TP_NREC) * rows * h->tp_max_seg));
+        TRY_OR_BAIL(dalloc(&h->d_tstart, rows * h->tp_max_seg * 8));
+        TRY_OR_BAIL(dalloc(&h->d_need, rows * h->tp_max_seg));
+        TRY_OR_BAIL(dalloc(&h->d_fin, rows));
+        TRY_OR_BAIL(hipMemset(h->d_fin, 0, rows * sizeof(mi::TpFinal)));
+    }
     TRY_OR_BAIL(mi::launch_init_state(h->d_state, h->d_carry, h->d_ring, h->d_ctcss_q, h->d_cp, nstreams, nch, p.n_ctcss_rows, h->own_stream));
     TRY_OR_BAIL(hipStreamSynchronize(h->own_stream));
 #undef TRY_OR_BAIL
@@ -449,6 +534,25 @@ int mi_demod_set_state(mi_demod* h, const void* buf, size_t len) {
     if (zrows)
         HIP_TRY(hipMemcpy2D(h->d_cplx, h->plane_stride * 8, o, mi::kAgcExtra * 8, mi::kAgcExtra * 8, zrows, hipMemcpyHostToDevice));
     h->first_call = hd.first_call != 0;
+    return MI_OK;
+}
+
+int mi_demod_last_path(mi_demod* h, int* time_parallel, int* unverified_rows) {
+    if (!h)
+        return fail(MI_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->gpu));
+    HIP_TRY(hipDeviceSynchronize());
+    if (time_parallel)
+        *time_parallel = h->last_path;
+    if (unverified_rows) {
+        *unverified_rows = 0;
+        if (h->last_path == 1) {
+            std::vector<mi::TpFinal> f(static_cast<size_t>(h->rows));
+            HIP_TRY(hipMemcpy(f.data(), h->d_fin, f.size() * sizeof(mi::TpFinal), hipMemcpyDeviceToHost));
+            for (const mi::TpFinal& x : f)
+                *unverified_rows += x.all_ok ? 0 : 1;
+        }
+    }
     return MI_OK;
 }
 

@@ -1,0 +1,769 @@
+// tp.hip -- time-parallel stage 2 for plain AM channels (no raw I/Q, no CTCSS, no notch), exact.
+//
+// The per-channel loop of demodulate() (rtl_airband.cpp:517-669) is a recurrence in time, so one stream
+// with 8 channels exposes 8 serial chains.  This file cuts a long HBM-resident capture into time
+// segments and still reproduces the serial result bit for bit.  Nothing here is approximate:
+//
+//  P1  k_tp_full    Squelch::pre_filter_.full_ (squelch.cpp:505) is a rounded EMA f' = fl(fl(f*0.99)+fl(x*b)),
+//                   monotone in f.  Each lane runs it over its segment twice, from a lower bound (0) and an
+//                   upper bound (1.0001 * max sample) of the true value, starting W1 steps early; once the
+//                   two trajectories are bitwise equal they ARE the true value (sandwich).  Per 16-sample
+//                   block it stores full at the block end, the block max of full, x[0] and min(x[1..15]);
+//                   a block whose start was not yet coalesced is marked invalid.
+//  A   k_tp_core    one wave per channel walks the blocks in order and keeps the exact
+//                   (noise_floor_, moving_avg_cap_, pre_filter_.capped_, pre_filter_.full_) (squelch.cpp:477-514).
+//                   Per block it first applies the noise-floor update, then one of
+//                     MERGED     capped == full, capped < cap and the block max of full < cap: the cap never
+//                                binds, so capped follows full: take P1's block-end value;
+//                     SATURATED  after the block's first sample capped == cap and every other sample >= cap:
+//                                capped stays cap (the reference's own shortcut, squelch.cpp:509-510);
+//                     STEP       otherwise: the 16 samples are stepped one by one.
+//                   It stores the exact core state at every segment boundary.
+//  B   k_tp_seg     one lane per (channel, segment of TP_L steps): the complete state machine + AM AGC + audio,
+//                   started TP_W steps early from the exact core state and a GUESSED state-machine/AGC state
+//                   (idle CLOSED).  It records the state it had at its segment start (S), runs the segment
+//                   writing audio, and records its end state (E).  Dead fields are canonicalised.
+//  C   k_tp_scan    per channel: segment k is accepted iff S_k equals E_{k-1} of an accepted predecessor
+//                   (agcavgfast only where segment k reads it; otherwise it is passed through).  By
+//                   induction from the true state at step 0 an accepted segment started from the true state,
+//                   so its audio and E_k are the serial result.
+//  D   k_tp_fix     segments that were not accepted are re-run from E_{k-1}; a re-run lane keeps going
+//                   through the following segments until its state meets their recorded S.
+//      (C, D) run twice, then k_tp_fallback re-runs serially whatever is still unaccepted, so the result
+//      never depends on the speculation succeeding -- only the speed does.
+//  E   k_tp_finish  applies the AM close-edge fades (rtl_airband.cpp:564-568) that were deferred as events,
+//                   reduces axcindicate per WAVE_BATCH and writes the carried state for the next call.
+//
+// Compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace mi {
+namespace {
+
+enum : int { SQ_CLOSED = 0, SQ_OPENING = 1, SQ_CLOSING = 2, SQ_LSA = 3, SQ_OPEN = 4 };
+constexpr int kOpenDelay = 197, kCloseDelay = 197, kLowSignalAbort = 88;
+constexpr int kRecent = 1000, kFlap = 3;
+
+// ---- the float recurrences, operation for operation (squelch.cpp:477-514) ----
+__device__ __forceinline__ float ema99(const float f, const float x) {
+    const float nfac = static_cast<float>(1.0 - static_cast<double>(0.99f));
+    return f * 0.99f + x * nfac;
+}
+__device__ __forceinline__ float capped_step(const float c, const float x, const float cap) {
+    if (c >= cap && x >= cap)
+        return cap;
+    const float e = ema99(c, x);
+    return (e < cap) ? e : cap;  // std::min(cap, e)
+}
+__device__ __forceinline__ float noise_floor_step(const float nf, const float c) {
+    const float nfac = static_cast<float>(1.0 - static_cast<double>(0.97f));
+    const float m = (nf < c) ? nf : c;  // std::min(capped, noise_floor)
+    return nf * 0.97f + m * nfac + 1e-6f;
+}
+__device__ __forceinline__ float cap_of(const ChanParams& p, const float nf) {
+    return p.using_manual_level ? p.manual_cap : p.cap_factor * nf;
+}
+__device__ __forceinline__ float level_of(const ChanParams& p, const float nf, const int recent) {
+    if (p.using_manual_level)
+        return p.manual_signal_level;
+    return ((recent >= kFlap && p.flappy_signal_ratio < p.normal_signal_ratio) ? p.flappy_signal_ratio : p.normal_signal_ratio) * nf;
+}
+
+// =====================================================================================================
+// P1: pre_filter_.full_ by sandwich, and the per-block aggregates
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_tp_full(const TpArgs a) {
+    const int lanes_per_row = (a.nsteps + TP_L1 - 1) / TP_L1;
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= a.nrows * lanes_per_row)
+        return;
+    const int r = gid / lanes_per_row, q = gid - r * lanes_per_row;
+    const int row = a.rows[r];
+    const float* __restrict__ x = a.mag + static_cast<size_t>(row) * a.plane_stride + kAgcExtra;
+    const uint32_t t0 = static_cast<uint32_t>(q) * TP_L1;
+    const uint32_t t1 = min(t0 + TP_L1, a.nsteps);
+    const uint32_t tw = t0 > TP_W1 ? t0 - TP_W1 : 0;
+    float lo, hi;
+    if (tw == 0) {
+        lo = hi = a.st[row].pre_full;  // the true value: exact from the first step
+    } else {
+        lo = 0.0f;
+        const float mx = fmaxf(__uint_as_float(a.xmax[row]), a.st[row].pre_full);
+        hi = mx * 1.0001f + 1e-30f;
+    }
+    for (uint32_t i = tw; i < t0; i += 4) {  // warm-up (tw and t0 are multiples of 16)
+        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        lo = ema99(lo, v.x), hi = ema99(hi, v.x);
+        lo = ema99(lo, v.y), hi = ema99(hi, v.y);
+        lo = ema99(lo, v.z), hi = ema99(hi, v.z);
+        lo = ema99(lo, v.w), hi = ema99(hi, v.w);
+    }
+    const size_t bbase = static_cast<size_t>(r) * a.nblk;
+    for (uint32_t i = t0; i < t1; i += 16) {
+        const bool valid = (lo == hi);
+        float fmax = 0.0f, xmin = 3.4e38f, x0 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i + j);
+            const float s[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lo = ema99(lo, s[k]);
+                hi = ema99(hi, s[k]);
+                fmax = fmaxf(fmax, hi);
+                if (j + k == 0)
+                    x0 = s[k];
+                else
+                    xmin = fminf(xmin, s[k]);
+            }
+        }
+        const size_t b = bbase + (i >> 4);
+        a.blk_fe[b] = hi;
+        a.blk_fm[b] = valid ? fmax : -1.0f;
+        a.blk_x0[b] = x0;
+        a.blk_xm[b] = xmin;
+    }
+}
+
+// =====================================================================================================
+// A: the exact core chain, one wave per channel
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
+    const int r = blockIdx.x;
+    const int row = a.rows[r];
+    const int lane = threadIdx.x;
+    const ChanParams p = a.cp[row % a.nch];
+    const float* __restrict__ x = a.mag + static_cast<size_t>(row) * a.plane_stride + kAgcExtra;
+    const size_t bbase = static_cast<size_t>(r) * a.nblk;
+    TpCore* __restrict__ core = a.core + static_cast<size_t>(r) * (a.nseg + 1);
+
+    // every lane carries the same values (the chain is wave-uniform); lanes differ only in what they prefetch
+    float nf = a.st[row].noise_floor, cap = a.st[row].moving_avg_cap, c = a.st[row].pre_capped, full = a.st[row].pre_full;
+    const uint32_t nblk = a.nblk;
+    constexpr uint32_t blocks_per_seg = TP_L / 16;
+
+    for (uint32_t g0 = 0; g0 < nblk; g0 += 64) {
+        const uint32_t mine = g0 + lane;
+        float v_fe = 0.f, v_fm = -1.f, v_x0 = 0.f, v_xm = 0.f;
+        if (mine < nblk) {
+            v_fe = a.blk_fe[bbase + mine];
+            v_fm = a.blk_fm[bbase + mine];
+            v_x0 = a.blk_x0[bbase + mine];
+            v_xm = a.blk_xm[bbase + mine];
+        }
+        const uint32_t nb = min(64u, nblk - g0);
+        for (uint32_t kk = 0; kk < nb; ++kk) {
+            const uint32_t blk = g0 + kk;
+            if (blk % blocks_per_seg == 0 && lane == 0) {
+                TpCore t;
+                t.nf = nf, t.cap = cap, t.c = c, t.full = full;
+                core[blk / blocks_per_seg] = t;
+            }
+            const float fe = __shfl(v_fe, kk), fm = __shfl(v_fm, kk), x0 = __shfl(v_x0, kk), xm = __shfl(v_xm, kk);
+            // squelch.cpp:212-214: the noise floor moves on the first sample of each block, from capped_ of the previous sample
+            nf = noise_floor_step(nf, c);
+            cap = cap_of(p, nf);
+            const bool valid = fm >= 0.0f;
+            if (valid && c == full && c < cap && fm < cap) {  // MERGED: the cap never binds in this block
+                c = fe;
+                full = fe;
+            } else {
+                const float c1 = capped_step(c, x0, cap);
+                if (c1 == cap && xm >= cap && valid) {  // SATURATED
+                    c = cap;
+                    full = fe;
+                } else {  // STEP
+                    float xs = 0.0f;
+                    if (lane < 16)
+                        xs = x[static_cast<size_t>(blk) * 16 + lane];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const float xj = __shfl(xs, j);
+                        full = ema99(full, xj);
+                        c = capped_step(c, xj, cap);
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        TpCore t;
+        t.nf = nf, t.cap = cap, t.c = c, t.full = full;
+        core[a.nseg] = t;
+    }
+}
+
+// =====================================================================================================
+// B / D: the segment engine
+// =====================================================================================================
+struct TpLane {
+    float nf, cap, c, full, level;
+    int cur, next, delay, low, recent, closed;
+    float agc;
+    int d_open, d_flappy, uses_agc, open_mask, nev;
+};
+
+struct TpFsm {  // canonical comparable part
+    int cur, next, delay, low, recent, closed;
+};
+
+__device__ __forceinline__ TpFsm canon(const TpLane& s) {
+    TpFsm f;
+    f.cur = s.cur;
+    f.next = s.next;
+    const bool delay_live = (s.next == SQ_OPENING && s.cur == SQ_OPENING) || (s.next == SQ_CLOSING && s.cur == SQ_CLOSING) ||
+                            (s.next == SQ_LSA && (s.cur == SQ_LSA || s.cur == SQ_CLOSING));
+    f.delay = delay_live ? s.delay : 0;
+    // low_signal_count_ is reset on entering OPENING and never read in CLOSED / LOW_SIGNAL_ABORT
+    f.low = (s.cur == SQ_OPENING || s.cur == SQ_CLOSING || s.cur == SQ_OPEN) ? s.low : 0;
+    f.recent = s.recent;
+    // closed_sample_count_ is rebuilt from 0 on every entry into CLOSED and read only at the end of OPENING
+    f.closed = (s.cur == SQ_CLOSED || s.cur == SQ_OPENING) ? s.closed : 0;
+    return f;
+}
+__device__ __forceinline__ bool same(const TpFsm& x, const TpFsm& y) {
+    return x.cur == y.cur && x.next == y.next && x.delay == y.delay && x.low == y.low && x.recent == y.recent && x.closed == y.closed;
+}
+
+// one sample of the loop for a plain AM channel; returns waveout[j]
+__device__ __forceinline__ float tp_step(TpLane& s, const ChanParams& p, const uint32_t i, const float x, const float aud,
+                                         const float* __restrict__ magrow, const bool in_seg, const uint32_t batch0, int* __restrict__ ev_slot,
+                                         const size_t ev_stride) {
+    // ---- Squelch::update_current_state, squelch.cpp:363-460 (no post filter, no CTCSS) ----
+    if (s.next == SQ_OPENING) {
+        if (s.cur != SQ_OPENING) {
+            s.delay = 0;
+            s.low = 0;
+            s.cur = SQ_OPENING;
+        } else {
+            s.delay++;
+            if (s.delay >= kOpenDelay) {
+                if (s.closed < kRecent) {
+                    s.recent++;
+                    if (s.recent >= kFlap && in_seg)
+                        s.d_flappy++;
+                    s.level = level_of(p, s.nf, s.recent);
+                }
+                s.next = (s.c >= s.level) ? SQ_OPEN : SQ_CLOSED;
+            }
+        }
+    } else if (s.next == SQ_CLOSING) {
+        if (s.cur != SQ_CLOSING) {
+            s.delay = 0;
+            s.cur = SQ_CLOSING;
+        } else {
+            s.delay++;
+            if (s.delay >= kCloseDelay) {
+                if (!(s.c >= s.level)) {
+                    s.next = SQ_CLOSED;
+                } else {
+                    s.cur = SQ_OPEN;
+                    s.next = SQ_OPEN;
+                }
+            }
+        }
+    } else if (s.next == SQ_LSA) {
+        if (s.cur != SQ_LSA) {
+            if (s.cur != SQ_CLOSING)
+                s.delay = 0;
+            s.cur = SQ_LSA;
+        } else {
+            s.delay++;
+            if (s.delay >= kCloseDelay)
+                s.next = SQ_CLOSED;
+        }
+    } else if (s.next == SQ_OPEN && s.cur != SQ_OPEN) {
+        if (in_seg)
+            s.d_open++;
+        s.cur = SQ_OPEN;
+    } else if (s.next == SQ_CLOSED && s.cur != SQ_CLOSED) {
+        s.closed = 0;
+        s.cur = SQ_CLOSED;
+    } else if (s.next == SQ_CLOSED && s.cur == SQ_CLOSED) {
+        if (s.closed < kRecent) {
+            s.closed++;
+        } else if (s.closed == kRecent) {
+            if (s.recent != 0) {
+                s.recent = 0;
+                s.level = level_of(p, s.nf, 0);
+            }
+        }
+    } else {
+        s.cur = s.next;
+    }
+    // ---- process_raw_sample, squelch.cpp:203-245 ----
+    if ((i & 15u) == 0) {
+        s.nf = noise_floor_step(s.nf, s.c);
+        s.cap = cap_of(p, s.nf);
+        s.level = level_of(p, s.nf, s.recent);
+    }
+    s.full = ema99(s.full, x);
+    s.c = capped_step(s.c, x, s.cap);
+    if (s.cur == SQ_OPEN && !(s.c >= s.level))
+        s.next = SQ_CLOSING;  // set_state(CLOSING) from OPEN
+    if (s.cur == SQ_CLOSED && (s.c >= s.level))
+        s.next = SQ_OPENING;  // set_state(OPENING) from CLOSED
+    if (s.cur != SQ_CLOSED && s.cur != SQ_LSA) {
+        if (x >= s.level) {
+            s.low = 0;
+        } else {
+            s.low++;
+            if (s.low >= kLowSignalAbort)
+                s.next = (s.cur == SQ_OPENING) ? SQ_CLOSED : SQ_LSA;  // set_state(LOW_SIGNAL_ABORT), squelch.cpp:338-341
+        }
+    }
+    // ---- AM edges, rtl_airband.cpp:554-569 ----
+    if (s.cur != SQ_OPEN && s.next == SQ_OPEN) {  // first_open_sample: bootstrap agcavgfast
+        for (int kk = 0; kk < kAgcExtra; ++kk) {
+            const float w = magrow[i + kk];
+            if (w >= s.level)
+                s.agc = s.agc * 0.9f + w * 0.1f;
+        }
+        if (in_seg)
+            s.uses_agc = 1;
+    } else if ((s.cur == SQ_CLOSING && s.next == SQ_CLOSED) || (s.cur != SQ_LSA && s.next == SQ_LSA)) {  // last_open_sample
+        if (in_seg && s.nev < TP_MAXEV) {  // rare: straight to the segment's record (events are >= 197 steps apart)
+            ev_slot[static_cast<size_t>(s.nev) * ev_stride] = static_cast<int>(i);
+            s.nev++;
+        }
+    }
+    // ---- audio, rtl_airband.cpp:574-641 ----
+    float wout = 0.0f;
+    if (s.cur == SQ_OPEN || s.cur == SQ_CLOSING) {
+        if (in_seg)
+            s.uses_agc = 1;
+        if (x > s.level)
+            s.agc = s.agc * 0.995f + x * 0.005f;
+        wout = (aud - s.agc) / (s.agc * 1.5f);
+        if (fabsf(wout) > 0.8f) {
+            wout *= 0.85f;
+            s.agc *= 1.15f;
+        }
+        wout *= p.ampfactor;
+        if (wout != wout)
+            wout = 0.0f;
+        else if (wout > 1.0f)
+            wout = 1.0f;
+        else if (wout < -1.0f)
+            wout = -1.0f;
+        if (in_seg)
+            s.open_mask |= ((i / kWaveBatch) == batch0) ? 1 : 2;
+    }
+    return wout;
+}
+
+__device__ __forceinline__ void out_store4(const TpArgs& a, const int row, const uint32_t i, const float4 v) {
+    // virtual waveout index of step i is AGC_EXTRA + i: [0, nsteps) emitted audio, the rest is the lookahead
+    const uint32_t vi = kAgcExtra + i;
+    if (vi < a.nsteps)
+        *reinterpret_cast<float4*>(a.wmain + static_cast<size_t>(row) * a.wmain_stride + vi) = v;
+    else
+        *reinterpret_cast<float4*>(a.carry + static_cast<size_t>(row) * kAgcExtra + (vi - a.nsteps)) = v;
+}
+
+// run steps [i0, i1) (multiples of 4); writes audio when in_seg
+__device__ __forceinline__ void tp_run(TpLane& s, const ChanParams& p, const TpArgs& a, const int row, const float* __restrict__ magrow,
+                                       const uint32_t i0, const uint32_t i1, const bool in_seg, const uint32_t batch0, const size_t rec_idx) {
+    if (i0 >= i1)
+        return;
+    int* __restrict__ ev_slot = a.rec + 19 * a.rec_stride + rec_idx;
+    const size_t ev_stride = a.rec_stride;
+    float4 xs = *reinterpret_cast<const float4*>(magrow + kAgcExtra + i0);
+    float4 as = *reinterpret_cast<const float4*>(magrow + i0);
+    for (uint32_t i = i0; i < i1; i += 4) {
+        const float4 xc = xs, ac = as;
+        if (i + 4 < i1) {  // next chunk in flight while this one is stepped
+            xs = *reinterpret_cast<const float4*>(magrow + kAgcExtra + i + 4);
+            as = *reinterpret_cast<const float4*>(magrow + i + 4);
+        }
+        float4 w;
+        w.x = tp_step(s, p, i, xc.x, ac.x, magrow, in_seg, batch0, ev_slot, ev_stride);
+        w.y = tp_step(s, p, i + 1, xc.y, ac.y, magrow, in_seg, batch0, ev_slot, ev_stride);
+        w.z = tp_step(s, p, i + 2, xc.z, ac.z, magrow, in_seg, batch0, ev_slot, ev_stride);
+        w.w = tp_step(s, p, i + 3, xc.w, ac.w, magrow, in_seg, batch0, ev_slot, ev_stride);
+        if (in_seg)
+            out_store4(a, row, i, w);
+    }
+}
+
+__device__ __forceinline__ void rec_store(const TpArgs& a, const size_t idx, const TpFsm& S, const float s_agc, const TpLane& e) {
+    int* __restrict__ rec = a.rec;
+    const size_t st = a.rec_stride;
+    rec[0 * st + idx] = S.cur;
+    rec[1 * st + idx] = S.next;
+    rec[2 * st + idx] = S.delay;
+    rec[3 * st + idx] = S.low;
+    rec[4 * st + idx] = S.recent;
+    rec[5 * st + idx] = S.closed;
+    rec[6 * st + idx] = __float_as_int(s_agc);
+    const TpFsm E = canon(e);
+    rec[7 * st + idx] = E.cur;
+    rec[8 * st + idx] = E.next;
+    rec[9 * st + idx] = E.delay;
+    rec[10 * st + idx] = E.low;
+    rec[11 * st + idx] = E.recent;
+    rec[12 * st + idx] = E.closed;
+    rec[13 * st + idx] = __float_as_int(e.agc);
+    rec[14 * st + idx] = e.uses_agc;
+    rec[15 * st + idx] = e.d_open;
+    rec[16 * st + idx] = e.d_flappy;
+    rec[17 * st + idx] = e.open_mask;
+    rec[18 * st + idx] = e.nev;  // the event steps themselves were written when they happened
+}
+
+__device__ __forceinline__ void seg_reset(TpLane& s) {
+    s.d_open = s.d_flappy = s.uses_agc = s.open_mask = s.nev = 0;
+}
+
+__device__ __forceinline__ void load_core(TpLane& s, const ChanParams& p, const TpCore& t) {
+    s.nf = t.nf, s.cap = t.cap, s.c = t.c, s.full = t.full;
+    s.level = level_of(p, s.nf, s.recent);
+}
+
+__global__ __launch_bounds__(64) void k_tp_seg(const TpArgs a) {
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= a.nrows * static_cast<int>(a.nseg))
+        return;
+    const int r = gid / a.nseg;
+    const uint32_t k = gid - r * a.nseg;
+    const int row = a.rows[r];
+    const ChanParams p = a.cp[row % a.nch];
+    const float* __restrict__ magrow = a.mag + static_cast<size_t>(row) * a.plane_stride;
+    const uint32_t s0 = k * TP_L, s1 = min(s0 + TP_L, a.nsteps);
+    const uint32_t wk = k > TP_W / TP_L ? k - TP_W / TP_L : 0;  // boundary index where the warm-up starts
+    TpLane s;
+    seg_reset(s);
+    if (wk == 0) {  // from the true state at the start of the call
+        const ChanState& cs = a.st[row];
+        s.cur = cs.current_state, s.next = cs.next_state, s.delay = cs.delay, s.low = cs.low_signal_count;
+        s.recent = static_cast<int>(cs.recent_open_count), s.closed = static_cast<int>(cs.closed_sample_count);
+        s.agc = cs.agcavgfast;
+    } else {  // guess: idle CLOSED; agcavgfast unknown (checked by the scan wherever it matters)
+        s.cur = s.next = SQ_CLOSED;
+        s.delay = s.low = s.recent = 0;
+        s.closed = kRecent;
+        s.agc = 0.5f;
+    }
+    load_core(s, p, a.core[static_cast<size_t>(r) * (a.nseg + 1) + wk]);
+    tp_run(s, p, a, row, magrow, wk * TP_L, s0, false, 0, static_cast<size_t>(r) * a.nseg + k);
+    const TpFsm S = canon(s);
+    const float s_agc = s.agc;
+    seg_reset(s);
+    tp_run(s, p, a, row, magrow, s0, s1, true, s0 / kWaveBatch, static_cast<size_t>(r) * a.nseg + k);
+    rec_store(a, static_cast<size_t>(r) * a.nseg + k, S, s_agc, s);
+}
+
+// =====================================================================================================
+// C: scan -- accept segments whose recorded start state equals the predecessor's end state
+// =====================================================================================================
+__device__ __forceinline__ TpFsm rec_fsm(const int* __restrict__ rec, const size_t st, const size_t idx, const int base) {
+    TpFsm f;
+    f.cur = rec[(base + 0) * st + idx];
+    f.next = rec[(base + 1) * st + idx];
+    f.delay = rec[(base + 2) * st + idx];
+    f.low = rec[(base + 3) * st + idx];
+    f.recent = rec[(base + 4) * st + idx];
+    f.closed = rec[(base + 5) * st + idx];
+    return f;
+}
+
+__global__ __launch_bounds__(64) void k_tp_scan(const TpArgs a) {
+    const int r = blockIdx.x;
+    const int row = a.rows[r];
+    const int lane = threadIdx.x;
+    const int* __restrict__ rec = a.rec;
+    const size_t st = a.rec_stride;
+    const size_t base = static_cast<size_t>(r) * a.nseg;
+
+    // the true state before step 0, canonical
+    TpLane init;
+    {
+        const ChanState& cs = a.st[row];
+        init.cur = cs.current_state, init.next = cs.next_state, init.delay = cs.delay, init.low = cs.low_signal_count;
+        init.recent = static_cast<int>(cs.recent_open_count), init.closed = static_cast<int>(cs.closed_sample_count);
+        init.agc = cs.agcavgfast;
+    }
+    TpFsm carryE = canon(init);
+    float carryA = init.agc;
+    bool all_ok = true;  // every segment so far accepted: carryE / carryA are the TRUE state
+    uint32_t first_bad = a.nseg;
+    int sum_open = 0, sum_flappy = 0;
+
+    for (uint32_t g0 = 0; g0 < a.nseg; g0 += 64) {
+        const uint32_t k = g0 + lane;
+        const bool have = k < a.nseg;
+        TpFsm S{}, E{};
+        float s_agc = 0.f, e_agc = 0.f;
+        int uses = 0, d_open = 0, d_flappy = 0;
+        if (have) {
+            S = rec_fsm(rec, st, base + k, 0);
+            E = rec_fsm(rec, st, base + k, 7);
+            s_agc = __int_as_float(rec[6 * st + base + k]);
+            e_agc = __int_as_float(rec[13 * st + base + k]);
+            uses = rec[14 * st + base + k];
+            d_open = rec[15 * st + base + k];
+            d_flappy = rec[16 * st + base + k];
+        }
+        // predecessor's end state
+        TpFsm P;
+        P.cur = __shfl_up(E.cur, 1), P.next = __shfl_up(E.next, 1), P.delay = __shfl_up(E.delay, 1);
+        P.low = __shfl_up(E.low, 1), P.recent = __shfl_up(E.recent, 1), P.closed = __shfl_up(E.closed, 1);
+        if (lane == 0)
+            P = carryE;
+        // agcavgfast before segment k = end value of the last earlier segment that touched it
+        const unsigned long long umask = __ballot(have && uses);
+        const unsigned long long below = umask & ((1ull << lane) - 1ull);
+        const int src = below ? 63 - __clzll(below) : 0;
+        const float a_from = __shfl(e_agc, src);
+        const float A = below ? a_from : carryA;
+        const bool ok = have && same(S, P) && (!uses || __float_as_int(s_agc) == __float_as_int(A));
+        if (have) {
+            // what a re-run of segment k has to start from (exact whenever every earlier segment was accepted)
+            int* __restrict__ ts = a.tstart;
+            const size_t ti = (base + k) * 8;
+            ts[ti + 0] = P.cur, ts[ti + 1] = P.next, ts[ti + 2] = P.delay, ts[ti + 3] = P.low;
+            ts[ti + 4] = P.recent, ts[ti + 5] = P.closed, ts[ti + 6] = __float_as_int(A);
+            a.need[base + k] = ok ? 0 : 1;
+        }
+        const unsigned long long okmask = __ballot(ok);
+        const unsigned long long havemask = __ballot(have);
+        const unsigned long long bad = havemask & ~okmask;
+        if (all_ok) {
+            // counters only over the accepted prefix
+            const int nacc = bad ? __ffsll(static_cast<long long>(bad)) - 1 : __popcll(havemask);
+            int o = (lane < nacc) ? d_open : 0, f = (lane < nacc) ? d_flappy : 0;
+            for (int off = 32; off > 0; off >>= 1) {
+                o += __shfl_xor(o, off);
+                f += __shfl_xor(f, off);
+            }
+            sum_open += o;
+            sum_flappy += f;
+            if (bad) {
+                all_ok = false;
+                first_bad = g0 + nacc;
+            }
+        }
+        // carry to the next group
+        const int lastl = __popcll(havemask) - 1;
+        carryE.cur = __shfl(E.cur, lastl), carryE.next = __shfl(E.next, lastl), carryE.delay = __shfl(E.delay, lastl);
+        carryE.low = __shfl(E.low, lastl), carryE.recent = __shfl(E.recent, lastl), carryE.closed = __shfl(E.closed, lastl);
+        if (umask) {
+            const int top = 63 - __clzll(umask);
+            carryA = __shfl(e_agc, top);
+        }
+    }
+    if (lane == 0) {
+        TpFinal f;
+        f.cur = carryE.cur, f.next = carryE.next, f.delay = carryE.delay, f.low = carryE.low, f.recent = carryE.recent, f.closed = carryE.closed;
+        f.agc = carryA;
+        f.all_ok = all_ok ? 1 : 0;
+        f.first_bad = first_bad;
+        f.d_open = sum_open;
+        f.d_flappy = sum_flappy;
+        a.fin[r] = f;
+    }
+}
+
+// =====================================================================================================
+// D: re-run segments that were not accepted
+// =====================================================================================================
+__device__ __forceinline__ void lane_from_tstart(TpLane& s, const int* __restrict__ ts) {
+    s.cur = ts[0], s.next = ts[1], s.delay = ts[2], s.low = ts[3], s.recent = ts[4], s.closed = ts[5];
+    s.agc = __int_as_float(ts[6]);
+}
+
+__device__ __forceinline__ void rerun_chain(const TpArgs& a, const int r, const int row, const ChanParams& p, uint32_t k, const uint32_t max_chain,
+                                            const bool stop_at_flagged, const bool to_the_end) {
+    const float* __restrict__ magrow = a.mag + static_cast<size_t>(row) * a.plane_stride;
+    const size_t base = static_cast<size_t>(r) * a.nseg;
+    TpLane s;
+    seg_reset(s);
+    lane_from_tstart(s, a.tstart + (base + k) * 8);
+    load_core(s, p, a.core[static_cast<size_t>(r) * (a.nseg + 1) + k]);
+    for (uint32_t done = 0; k < a.nseg; ++k, ++done) {
+        if (done > 0 && !to_the_end) {
+            if (done >= max_chain)
+                return;
+            if (stop_at_flagged && a.need[base + k])
+                return;  // that segment has its own lane
+            // does the running state meet what segment k's lane recorded at its start?
+            const TpFsm S = rec_fsm(a.rec, a.rec_stride, base + k, 0);
+            const int uses = a.rec[14 * a.rec_stride + base + k];
+            const int sagc = a.rec[6 * a.rec_stride + base + k];
+            if (same(canon(s), S) && (!uses || sagc == __float_as_int(s.agc)))
+                return;
+        }
+        const uint32_t s0 = k * TP_L, s1 = min(s0 + TP_L, a.nsteps);
+        const TpFsm S = canon(s);
+        const float s_agc = s.agc;
+        seg_reset(s);
+        tp_run(s, p, a, row, magrow, s0, s1, true, s0 / kWaveBatch, base + k);
+        rec_store(a, base + k, S, s_agc, s);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_tp_fix(const TpArgs a) {
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= a.nrows * static_cast<int>(a.nseg))
+        return;
+    const int r = gid / a.nseg;
+    const uint32_t k = gid - r * a.nseg;
+    if (!a.need[static_cast<size_t>(r) * a.nseg + k])
+        return;
+    const int row = a.rows[r];
+    const ChanParams p = a.cp[row % a.nch];
+    rerun_chain(a, r, row, p, k, TP_MAXCHAIN, true, false);
+}
+
+// last resort: one lane per channel re-runs serially everything from the first unaccepted segment
+__global__ __launch_bounds__(64) void k_tp_fallback(const TpArgs a) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= a.nrows)
+        return;
+    const TpFinal f = a.fin[r];
+    if (f.all_ok)
+        return;
+    const int row = a.rows[r];
+    const ChanParams p = a.cp[row % a.nch];
+    // tstart of first_bad was written from an accepted predecessor: it is the true state
+    rerun_chain(a, r, row, p, f.first_bad, 0xffffffffu, false, true);
+}
+
+// =====================================================================================================
+// E: deferred fades, axcindicate, carried state
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_tp_fades(const TpArgs a) {
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= a.nrows * static_cast<int>(a.nseg))
+        return;
+    const int r = gid / a.nseg;
+    const uint32_t k = gid - r * a.nseg;
+    const int row = a.rows[r];
+    const size_t idx = static_cast<size_t>(r) * a.nseg + k;
+    const int nev = a.rec[18 * a.rec_stride + idx];
+    float* __restrict__ wmain = a.wmain + static_cast<size_t>(row) * a.wmain_stride;
+    float* __restrict__ carry = a.carry + static_cast<size_t>(row) * kAgcExtra;
+    for (int e = 0; e < nev && e < TP_MAXEV; ++e) {
+        const uint32_t i = static_cast<uint32_t>(a.rec[(19 + e) * a.rec_stride + idx]);
+        // rtl_airband.cpp:564-568: waveout[k] = waveout[k-1] * 0.94 for k = j-99 .. j-1, in virtual indices i+1 .. i+99
+        float v = (i < a.nsteps) ? wmain[i] : carry[i - a.nsteps];
+        for (int kk = 1; kk < kAgcExtra; ++kk) {
+            v = v * 0.94f;
+            const uint32_t vi = i + kk;
+            if (vi < a.nsteps)
+                wmain[vi] = v;
+            else
+                carry[vi - a.nsteps] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_tp_finish(const TpArgs a) {
+    const int r = blockIdx.x;
+    const int row = a.rows[r];
+    const int lane = threadIdx.x;
+    const size_t base = static_cast<size_t>(r) * a.nseg;
+    // axcindicate per WAVE_BATCH from the segments' open masks
+    int nopen = 0;
+    for (uint32_t b = lane; b < a.nbatches; b += 64) {
+        const uint32_t kmin = (b * kWaveBatch) / TP_L, kmax = min((b * kWaveBatch + kWaveBatch - 1) / TP_L, a.nseg - 1);
+        bool open = false;
+        for (uint32_t k = kmin; k <= kmax; ++k) {
+            const int m = a.rec[17 * a.rec_stride + base + k];
+            const bool first = ((k * TP_L) / kWaveBatch) == b;
+            open |= first ? (m & 1) != 0 : (m & 2) != 0;
+        }
+        a.axc[static_cast<size_t>(row) * a.nbatches + b] = open ? MI_SIGNAL : MI_NO_SIGNAL;
+        nopen += open ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        nopen += __shfl_xor(nopen, off);
+    // the magnitude plane's last AGC_EXTRA samples move to the front (rtl_airband.cpp:643)
+    float* __restrict__ magrow = a.mag + static_cast<size_t>(row) * a.plane_stride;
+    for (int v = lane; v < kAgcExtra; v += 64)
+        magrow[v] = magrow[a.nsteps + v];
+    if (lane != 0)
+        return;
+    const TpFinal f = a.fin[r];
+    const TpCore t = a.core[static_cast<size_t>(r) * (a.nseg + 1) + a.nseg];
+    const ChanParams p = a.cp[row % a.nch];
+    ChanState cs = a.st[row];
+    cs.noise_floor = t.nf;
+    cs.moving_avg_cap = t.cap;
+    cs.pre_capped = t.c;
+    cs.pre_full = t.full;
+    cs.squelch_level_cache = 0.0f;  // a pure function of (recent_open_count_, noise_floor_): refilled on first use
+    cs.current_state = f.cur;
+    cs.next_state = f.next;
+    cs.delay = f.delay;
+    cs.low_signal_count = f.low;
+    cs.recent_open_count = static_cast<uint32_t>(f.recent);
+    cs.closed_sample_count = static_cast<uint32_t>(f.closed);
+    cs.sample_count += a.nsteps;
+    cs.buffer_head = static_cast<int32_t>((static_cast<uint32_t>(cs.buffer_head) + a.nsteps) % kSquelchRing);
+    cs.buffer_tail = static_cast<int32_t>((static_cast<uint32_t>(cs.buffer_tail) + a.nsteps) % kSquelchRing);
+    cs.open_count += static_cast<uint64_t>(f.d_open);
+    cs.flappy_count += static_cast<uint64_t>(f.d_flappy);
+    cs.agcavgfast = f.agc;
+    cs.active_counter += static_cast<uint64_t>(nopen);
+    a.st[row] = cs;
+    if (a.stats) {
+        mi_channel_stats s{};
+        s.noise_level = cs.noise_floor;
+        s.signal_level = cs.pre_full;
+        s.squelch_level = level_of(p, cs.noise_floor, f.recent);
+        s.agcavgfast = cs.agcavgfast;
+        s.open_count = cs.open_count;
+        s.flappy_count = cs.flappy_count;
+        s.ctcss_count = s.no_ctcss_count = 0;
+        s.active_counter = cs.active_counter;
+        s.squelch_state = cs.current_state;
+        s.signal_outside_filter = 0;
+        a.stats[row] = s;
+    }
+}
+
+// head of the emitted audio = lookahead of the previous call (output.cpp:948); runs before any segment writes
+__global__ void k_tp_prologue(const TpArgs a) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= a.nrows * kAgcExtra)
+        return;
+    const int r = gid / kAgcExtra, v = gid - r * kAgcExtra;
+    const int row = a.rows[r];
+    a.wmain[static_cast<size_t>(row) * a.wmain_stride + v] = a.carry[static_cast<size_t>(row) * kAgcExtra + v];
+}
+
+}  // namespace
+
+#define TP_LAUNCH(kern, grid, block)                              \
+    do {                                                          \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, a); \
+        hipError_t e__ = hipGetLastError();                       \
+        if (e__ != hipSuccess)                                    \
+            return e__;                                           \
+    } while (0)
+
+hipError_t launch_tp(const TpArgs& a, hipStream_t s) {
+    if (a.nrows == 0 || a.nsteps == 0)
+        return hipSuccess;
+    const int lanes1 = a.nrows * static_cast<int>((a.nsteps + TP_L1 - 1) / TP_L1);
+    const int lanes = a.nrows * static_cast<int>(a.nseg);
+    TP_LAUNCH(k_tp_prologue, (a.nrows * kAgcExtra + 255) / 256, 256);
+    TP_LAUNCH(k_tp_full, (lanes1 + 63) / 64, 64);
+    TP_LAUNCH(k_tp_core, a.nrows, 64);
+    TP_LAUNCH(k_tp_seg, (lanes + 63) / 64, 64);
+    for (int round = 0; round < 2; ++round) {
+        TP_LAUNCH(k_tp_scan, a.nrows, 64);
+        TP_LAUNCH(k_tp_fix, (lanes + 63) / 64, 64);
+    }
+    TP_LAUNCH(k_tp_scan, a.nrows, 64);
+    TP_LAUNCH(k_tp_fallback, (a.nrows + 63) / 64, 64);
+    TP_LAUNCH(k_tp_scan, a.nrows, 64);
+    TP_LAUNCH(k_tp_fades, (lanes + 63) / 64, 64);
+    TP_LAUNCH(k_tp_finish, a.nrows, 64);
+    return hipSuccess;
+}
+
+}  // namespace mi

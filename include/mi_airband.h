@@ -138,6 +138,12 @@ size_t mi_demod_state_size(const mi_demod* h);
 int mi_demod_get_state(mi_demod* h, void* buf, size_t len);
 int mi_demod_set_state(mi_demod* h, const void* buf, size_t len);
 
+/* Which stage-2 path the last call took: the serial per-channel kernel (0) or the time-parallel one (1,
+ * plain AM channels and long enough calls; DESIGN.md "Time-parallel stage 2").  unverified_rows counts
+ * channels whose segment chain was not fully accepted after the serial fallback -- always 0; it exists so
+ * the tests can assert that.  Synchronises. */
+int mi_demod_last_path(mi_demod* h, int* time_parallel, int* unverified_rows);
+
 /* Diagnostic view of stage 1's output as stage 2 left it after the last call (synchronises): the
  * magnitude plane of (stream, ch), plane index 0 = the oldest carried sample; after a call of n steps
  * indices [0, AGC_EXTRA) hold the carry for the next call.  iq may be NULL; it is only filled for

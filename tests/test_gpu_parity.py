@@ -204,3 +204,93 @@ def test_error_paths(pkg):
     with pytest.raises(pkg.MiError):
         d.process([np.zeros(d.bytes_needed(3), np.uint8)], 3)  # more than max_batches
     d.close()
+
+
+# ---------------- time-parallel stage 2 (plain AM channels, long calls) ----------------
+
+def _tp_run(pkg, dev, chans, iq, calls, monkeypatch, force="1"):
+    """Run `calls` = [nbatches, ...] consecutive calls on one handle; returns audio, flags, stats and paths."""
+    monkeypatch.setenv("MI_AIRBAND_TP", force)
+    d = pkg.Demod(dev, chans, nstreams=1, max_batches=max(calls))
+    outs, flags, paths = [], [], []
+    done = 0
+    for k in calls:
+        pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+        wo, axc, _, st = d.process([iq[pos:]], k)
+        outs.append(wo[:, :, :k * WAVE_BATCH])
+        flags.append(axc)
+        paths.append(d.last_path())
+        done += k
+    d.close()
+    return np.concatenate(outs, axis=2), np.concatenate(flags, axis=2), st, paths
+
+
+def test_time_parallel_config2_equals_oracle(pkg, monkeypatch):
+    """64 batches (8 s) of BASELINE configs[1] through the time-parallel path in one call."""
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    nbat = 64
+    iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=2)
+    nb, owo, oaxc, _ = oracle_run(dev, chans, iq, nbat)
+    assert nb == nbat
+    wo, axc, st, paths = _tp_run(pkg, dev, chans, iq, [nbat], monkeypatch)
+    assert paths == [(1, 0)], "expected the time-parallel path with every segment verified"
+    assert_same(axc[0], oaxc, "axcindicate (time-parallel)")
+    assert_same(wo[0], owo, "audio (time-parallel)")
+    assert st[0].open_count >= 3 and st[1].open_count == 0
+
+
+def test_time_parallel_streaming_calls_and_path_switch(pkg, monkeypatch):
+    """State carried across calls of mixed sizes, alternating between the time-parallel and the serial kernel."""
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    calls = [9, 1, 17, 3, 10]
+    nbat = sum(calls)
+    iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=5)
+    nb, owo, oaxc, _ = oracle_run(dev, chans, iq, nbat)
+    monkeypatch.delenv("MI_AIRBAND_TP", raising=False)
+    d = pkg.Demod(dev, chans, nstreams=1, max_batches=max(calls))
+    outs, flags, paths, done = [], [], [], 0
+    for k in calls:
+        pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+        wo, axc, _, st = d.process([iq[pos:]], k)
+        outs.append(wo[:, :, :k * WAVE_BATCH])
+        flags.append(axc)
+        paths.append(d.last_path()[0])
+        done += k
+    d.close()
+    assert paths == [1, 0, 1, 0, 1]
+    assert_same(np.concatenate(flags, axis=2)[0], oaxc, "axcindicate")
+    assert_same(np.concatenate(outs, axis=2)[0], owo, "audio")
+    # counters and levels at the end equal an all-serial run
+    monkeypatch.setenv("MI_AIRBAND_TP", "0")
+    d2 = pkg.Demod(dev, chans, nstreams=1, max_batches=nbat)
+    _, _, _, st2 = d2.process([iq], nbat)
+    d2.close()
+    for c in range(len(chans)):
+        for f in ("noise_level", "signal_level", "squelch_level", "agcavgfast", "open_count", "flappy_count", "active_counter", "squelch_state"):
+            assert getattr(st[c], f) == getattr(st2[c], f), (c, f)
+
+
+def test_time_parallel_hard_signals(pkg, monkeypatch):
+    """Flapping (rapid on/off), manual and low-SNR squelch, weak marginal carriers, ampfactor: the cases where
+    the guessed segment start states are wrong and the scan / fix / fallback chain has to earn its keep."""
+    centre = 120000000
+    chans = [pkg.channel_cfg(centre + 250000), pkg.channel_cfg(centre - 250000, squelch_threshold_dbfs=-45),
+             pkg.channel_cfg(centre + 500000, squelch_snr_db=2.0, ampfactor=3.0), pkg.channel_cfg(centre - 500000, squelch_snr_db=0.0),
+             pkg.channel_cfg(centre + 750000), pkg.channel_cfg(centre - 750000, squelch_snr_db=14.0)]
+    dev = pkg.device_cfg(centerfreq=centre)
+    nbat = 48
+    n = bytes_for_batches(dev, nbat) // 2
+    # gate period 0.03 s: carriers toggle every 480 output samples -> squelch re-opens within the "recent" window
+    carriers = [(250000, 0, 3072, 0), (-250000, 0, 900, 1), (500000, 0, 400, 0), (-500000, 0, 2000, 1), (750000, 0, 160, 0),
+                (-750000, 0, 700, 1)]
+    cfg = pkg.iqgen_cfg(sample_rate=dev.sample_rate, gate_samples=76800, carriers=carriers)
+    iq = pkg.iqgen_host(cfg, 0, 0, n)
+    nb, owo, oaxc, _ = oracle_run(dev, chans, iq, nbat)
+    assert nb == nbat
+    wo, axc, st, paths = _tp_run(pkg, dev, chans, iq, [nbat], monkeypatch)
+    assert paths[0][0] == 1 and paths[0][1] == 0
+    assert_same(axc[0], oaxc, "axcindicate")
+    assert_same(wo[0], owo, "audio")
+    assert max(s.flappy_count for s in st) > 0, "the input was meant to trigger flap detection"
