@@ -79,7 +79,7 @@ class IqGenCfg(C.Structure):
 ABI_SYMBOLS = [
     "mi_last_error", "mi_device_count", "mi_demod_create", "mi_demod_destroy", "mi_demod_bytes_needed", "mi_demod_bytes_consumed",
     "mi_demod_hop_bytes", "mi_demod_process", "mi_demod_process_device", "mi_demod_get_stats", "mi_demod_state_size",
-    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
+    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_tp_debug","mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
     "mi_plan_window", "mi_plan_twiddles", "mi_plan_levels", "mi_plan_sincos_lut", "mi_plan_channel", "mi_plan_ctcss_coeffs",
     "mi_iqgen_host", "mi_iqgen_device",
 ]
@@ -113,6 +113,7 @@ def lib():
         L.mi_demod_get_state.argtypes = [vp, vp, sz]
         L.mi_demod_set_state.argtypes = [vp, vp, sz]
         L.mi_demod_last_path.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mi_demod_tp_debug.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_int)]
         L.mi_demod_read_planes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.mi_demod_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mi_plan_create.argtypes = [C.POINTER(DeviceCfg), C.POINTER(ChannelCfg), C.c_int, C.POINTER(vp)]
@@ -269,6 +270,16 @@ class Demod:
         a, b = C.c_int(0), C.c_int(0)
         _check(lib().mi_demod_last_path(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def tp_debug(self, row):
+        """(core[nseg+1][4], diag[4]) of the last time-parallel call for one row."""
+        nseg = C.c_int(0)
+        _check(lib().mi_demod_tp_debug(self._h, row, None, 0, None, C.byref(nseg)))
+        core = np.zeros((nseg.value + 1, 4), np.float32)
+        diag = np.zeros(8, np.int32)
+        _check(lib().mi_demod_tp_debug(self._h, row, core.ctypes.data_as(C.c_void_p), nseg.value + 1, diag.ctypes.data_as(C.c_void_p),
+                                       C.byref(nseg)))
+        return core, diag
 
     def read_planes(self, stream, ch, first, count, want_iq=False):
         mag = np.zeros(count, np.float32)

@@ -127,6 +127,8 @@ struct TpArgs {
     int* tstart;                               // [nrows*nseg][8]
     int* need;                                 // [nrows*nseg]
     TpFinal* fin;                              // [nrows]
+    int* diag;                                 // [nrows][4]: segments not accepted in scan 0..3
+    int scan_round;
 };
 
 hipError_t launch_tp(const TpArgs& a, hipStream_t s);

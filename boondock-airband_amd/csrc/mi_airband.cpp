@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -93,6 +94,8 @@ struct mi_demod {
     int* d_tstart = nullptr;
     int* d_need = nullptr;
     mi::TpFinal* d_fin = nullptr;
+    int* d_diag = nullptr;
+    uint32_t last_nseg = 0;
     size_t tp_max_blk = 0, tp_max_seg = 0;
 };
 
@@ -207,6 +210,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.tstart = h->d_tstart;
         ta.need = h->d_need;
         ta.fin = h->d_fin;
+        ta.diag = h->d_diag;
+        h->last_nseg = ta.nseg;
         HIP_TRY(mi::launch_tp(ta, s));
     } else {
         HIP_TRY(mi::launch_demod(da, s));
@@ -239,7 +244,7 @@ void mi_demod_destroy(mi_demod* h) {
     (void)hipSetDevice(h->gpu);
     void* ptrs[] = {h->d_window, h->d_tw,   h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_mag,   h->d_cplx, h->d_carry,
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc,
-                    h->d_rows,   h->d_xmax, h->d_blk_fe, h->d_blk_fm, h->d_blk_x0, h->d_blk_xm, h->d_core, h->d_rec, h->d_tstart, h->d_need, h->d_fin};
+                    h->d_rows,   h->d_xmax, h->d_blk_fe, h->d_blk_fm, h->d_blk_x0, h->d_blk_xm, h->d_core, h->d_rec, h->d_tstart, h->d_need, h->d_fin, h->d_diag};
     for (void* p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -356,6 +361,8 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
         TRY_OR_BAIL(dalloc(&h->d_need, rows * h->tp_max_seg));
         TRY_OR_BAIL(dalloc(&h->d_fin, rows));
         TRY_OR_BAIL(hipMemset(h->d_fin, 0, rows * sizeof(mi::TpFinal)));
+        TRY_OR_BAIL(dalloc(&h->d_diag, rows * 8));
+        TRY_OR_BAIL(hipMemset(h->d_diag, 0, rows * 8 * sizeof(int)));
     }
     TRY_OR_BAIL(mi::launch_init_state(h->d_state, h->d_carry, h->d_ring, h->d_ctcss_q, h->d_cp, nstreams, nch, p.n_ctcss_rows, h->own_stream));
     TRY_OR_BAIL(hipStreamSynchronize(h->own_stream));
@@ -552,6 +559,24 @@ int mi_demod_last_path(mi_demod* h, int* time_parallel, int* unverified_rows) {
             for (const mi::TpFinal& x : f)
                 *unverified_rows += x.all_ok ? 0 : 1;
         }
+    }
+    return MI_OK;
+}
+
+int mi_demod_tp_debug(mi_demod* h, int row, float* core4, int max_entries, int* diag4, int* nseg) {
+    if (!h || row < 0 || row >= h->rows || !h->tp_eligible || h->last_path != 1)
+        return fail(MI_ERR_INVALID, "the last call did not take the time-parallel path");
+    HIP_TRY(hipSetDevice(h->gpu));
+    HIP_TRY(hipDeviceSynchronize());
+    if (nseg)
+        *nseg = static_cast<int>(h->last_nseg);
+    if (core4) {
+        const size_t n = std::min<size_t>(static_cast<size_t>(max_entries), h->last_nseg + 1);
+        HIP_TRY(hipMemcpy(core4, h->d_core + static_cast<size_t>(row) * (h->last_nseg + 1), n * sizeof(mi::TpCore), hipMemcpyDeviceToHost));
+    }
+    if (diag4) {  // [0..3] scan rounds, [4..7] core-chain blocks: in accepted runs, single O(1), stepped, failed hypotheses
+        HIP_TRY(hipMemcpy(diag4, h->d_diag + static_cast<size_t>(row) * 4, 4 * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(diag4 + 4, h->d_diag + static_cast<size_t>(h->rows) * 4 + static_cast<size_t>(row) * 4, 4 * sizeof(int), hipMemcpyDeviceToHost));
     }
     return MI_OK;
 }

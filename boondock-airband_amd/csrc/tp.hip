@@ -52,10 +52,9 @@ __device__ __forceinline__ float ema99(const float f, const float x) {
     return f * 0.99f + x * nfac;
 }
 __device__ __forceinline__ float capped_step(const float c, const float x, const float cap) {
-    if (c >= cap && x >= cap)
-        return cap;
     const float e = ema99(c, x);
-    return (e < cap) ? e : cap;  // std::min(cap, e)
+    const float m = (e < cap) ? e : cap;          // std::min(cap, e)
+    return (c >= cap && x >= cap) ? cap : m;      // squelch.cpp:509-510 (branch-free: same values)
 }
 __device__ __forceinline__ float noise_floor_step(const float nf, const float c) {
     const float nfac = static_cast<float>(1.0 - static_cast<double>(0.97f));
@@ -130,6 +129,40 @@ __global__ __launch_bounds__(64) void k_tp_full(const TpArgs a) {
 // =====================================================================================================
 // A: the exact core chain, one wave per channel
 // =====================================================================================================
+// wave-uniform lane read / write (v_readlane_b32 / v_writelane_b32: no LDS round trip)
+__device__ __forceinline__ float rl(const float v, const int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float wl(const float vec, const float val, const int lane) {
+    return (static_cast<int>(threadIdx.x) == lane) ? val : vec;  // v_cmp + v_cndmask with a scalar lane index
+}
+
+struct CoreGroup {  // what lane l holds for block g0 + l
+    float fe, fm, x0, xm;
+    float4 s0, s1, s2, s3;  // the block's 16 raw samples (only read when the block has to be stepped)
+};
+
+__device__ __forceinline__ CoreGroup core_load(const TpArgs& a, const float* __restrict__ x, const size_t bbase, const uint32_t g0, const int lane) {
+    CoreGroup g;
+    g.fe = 0.f, g.fm = -1.f, g.x0 = 0.f, g.xm = 0.f;
+    g.s0 = g.s1 = g.s2 = g.s3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t mine = g0 + lane;
+    if (mine < a.nblk) {
+        g.fe = a.blk_fe[bbase + mine];
+        g.fm = a.blk_fm[bbase + mine];
+        g.x0 = a.blk_x0[bbase + mine];
+        g.xm = a.blk_xm[bbase + mine];
+        const float4* __restrict__ sp = reinterpret_cast<const float4*>(x + static_cast<size_t>(mine) * 16);
+        g.s0 = sp[0], g.s1 = sp[1], g.s2 = sp[2], g.s3 = sp[3];
+    }
+    return g;
+}
+
+__device__ __forceinline__ int trailing_ones_from(const unsigned long long okmask, const int kk) {
+    const unsigned long long m = okmask >> kk;
+    return (~m == 0ull) ? 64 - kk : __ffsll(static_cast<long long>(~m)) - 1;
+}
+
 __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
     const int r = blockIdx.x;
     const int row = a.rows[r];
@@ -139,59 +172,124 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
     const size_t bbase = static_cast<size_t>(r) * a.nblk;
     TpCore* __restrict__ core = a.core + static_cast<size_t>(r) * (a.nseg + 1);
 
-    // every lane carries the same values (the chain is wave-uniform); lanes differ only in what they prefetch
+    // every lane carries the same chain values (wave-uniform); lanes differ in the block they prefetched
     float nf = a.st[row].noise_floor, cap = a.st[row].moving_avg_cap, c = a.st[row].pre_capped, full = a.st[row].pre_full;
     const uint32_t nblk = a.nblk;
-    constexpr uint32_t blocks_per_seg = TP_L / 16;
+    constexpr uint32_t bps = TP_L / 16;  // blocks per segment
 
+    int n_run = 0, n_single = 0, n_step = 0, n_fail = 0;  // diagnostics: blocks per path, failed hypotheses
+    CoreGroup nxt = core_load(a, x, bbase, 0, lane);
     for (uint32_t g0 = 0; g0 < nblk; g0 += 64) {
-        const uint32_t mine = g0 + lane;
-        float v_fe = 0.f, v_fm = -1.f, v_x0 = 0.f, v_xm = 0.f;
-        if (mine < nblk) {
-            v_fe = a.blk_fe[bbase + mine];
-            v_fm = a.blk_fm[bbase + mine];
-            v_x0 = a.blk_x0[bbase + mine];
-            v_xm = a.blk_xm[bbase + mine];
-        }
-        const uint32_t nb = min(64u, nblk - g0);
-        for (uint32_t kk = 0; kk < nb; ++kk) {
+        const CoreGroup cur = nxt;
+        if (g0 + 64 < nblk)
+            nxt = core_load(a, x, bbase, g0 + 64, lane);  // in flight while this group is walked
+        const int nb = static_cast<int>(min(64u, nblk - g0));
+        const float fe_prev = __shfl_up(cur.fe, 1);  // full_ at the start of lane's block, valid for lane > kk
+        const bool boundary = ((g0 + lane) % bps) == 0;
+        int kk = 0;
+        while (kk < nb) {
+            if (c == full || c == cap) {
+                // Hypothesis: the regime of the current block persists.  The noise-floor chain is walked serially
+                // (the only true dependence), every block's precondition is then checked by its own lane.
+                const bool merged = (c == full);
+                float vnf = 0.0f, vprev = 0.0f;  // lane j: noise floor after / before block j's update
+                if (merged) {
+                    float nfc = nf, cc = c;
+                    for (int j = kk; j < nb; ++j) {
+                        vprev = wl(vprev, nfc, j);
+                        nfc = noise_floor_step(nfc, cc);
+                        vnf = wl(vnf, nfc, j);
+                        cc = rl(cur.fe, j);  // capped_ == full_ at the end of block j under the hypothesis
+                    }
+                } else {
+                    float nfc = nf, cc = c;
+                    for (int j = kk; j < nb; ++j) {
+                        vprev = wl(vprev, nfc, j);
+                        nfc = noise_floor_step(nfc, cc);
+                        vnf = wl(vnf, nfc, j);
+                        cc = cap_of(p, nfc);  // capped_ == cap at the end of block j under the hypothesis
+                    }
+                }
+                // (no cross-lane read here: a shuffle sunk under `lane != kk` would see lane kk inactive and return 0)
+                const float nf_prev = vprev;
+                const float cap_prev = (lane == kk) ? cap : cap_of(p, nf_prev);
+                const float capj = cap_of(p, vnf);
+                const float full_entry = (lane == kk) ? full : fe_prev;
+                const float c_entry = merged ? full_entry : cap_prev;
+                bool ok = lane >= kk && lane < nb && cur.fm >= 0.0f;
+                if (merged)
+                    ok = ok && c_entry < capj && cur.fm < capj;  // MERGED: the cap never binds inside the block
+                else
+                    ok = ok && capped_step(c_entry, cur.x0, capj) == capj && cur.xm >= capj;  // SATURATED
+                const int nacc = min(trailing_ones_from(__ballot(ok), kk), nb - kk);
+                if (nacc > 0) {
+                    if (boundary && lane >= kk && lane < kk + nacc) {
+                        TpCore t;
+                        t.nf = nf_prev, t.cap = cap_prev, t.c = c_entry, t.full = full_entry;
+                        core[(g0 + lane) / bps] = t;
+                    }
+                    const int last = kk + nacc - 1;
+                    nf = rl(vnf, last);
+                    cap = cap_of(p, nf);
+                    full = rl(cur.fe, last);
+                    c = merged ? full : cap;
+                    kk += nacc;
+                    n_run += nacc;
+                    continue;
+                }
+                ++n_fail;
+            }
+            // one block, no hypothesis
             const uint32_t blk = g0 + kk;
-            if (blk % blocks_per_seg == 0 && lane == 0) {
+            if (blk % bps == 0 && lane == 0) {
                 TpCore t;
                 t.nf = nf, t.cap = cap, t.c = c, t.full = full;
-                core[blk / blocks_per_seg] = t;
+                core[blk / bps] = t;
             }
-            const float fe = __shfl(v_fe, kk), fm = __shfl(v_fm, kk), x0 = __shfl(v_x0, kk), xm = __shfl(v_xm, kk);
+            const float fe = rl(cur.fe, kk), fm = rl(cur.fm, kk), x0 = rl(cur.x0, kk), xm = rl(cur.xm, kk);
             // squelch.cpp:212-214: the noise floor moves on the first sample of each block, from capped_ of the previous sample
             nf = noise_floor_step(nf, c);
             cap = cap_of(p, nf);
             const bool valid = fm >= 0.0f;
-            if (valid && c == full && c < cap && fm < cap) {  // MERGED: the cap never binds in this block
+            if (valid && c == full && c < cap && fm < cap) {  // MERGED
                 c = fe;
                 full = fe;
-            } else {
-                const float c1 = capped_step(c, x0, cap);
-                if (c1 == cap && xm >= cap && valid) {  // SATURATED
-                    c = cap;
+                ++n_single;
+            } else if (valid && capped_step(c, x0, cap) == cap && xm >= cap) {  // SATURATED
+                c = cap;
+                full = fe;
+                ++n_single;
+            } else {  // STEP: the 16 samples one by one
+                ++n_step;
+                const float xs[16] = {rl(cur.s0.x, kk), rl(cur.s0.y, kk), rl(cur.s0.z, kk), rl(cur.s0.w, kk), rl(cur.s1.x, kk), rl(cur.s1.y, kk),
+                                      rl(cur.s1.z, kk), rl(cur.s1.w, kk), rl(cur.s2.x, kk), rl(cur.s2.y, kk), rl(cur.s2.z, kk), rl(cur.s2.w, kk),
+                                      rl(cur.s3.x, kk), rl(cur.s3.y, kk), rl(cur.s3.z, kk), rl(cur.s3.w, kk)};
+                if (valid) {  // full_ at the block end is already known exactly
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        c = capped_step(c, xs[j], cap);
                     full = fe;
-                } else {  // STEP
-                    float xs = 0.0f;
-                    if (lane < 16)
-                        xs = x[static_cast<size_t>(blk) * 16 + lane];
+                } else {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
-                        const float xj = __shfl(xs, j);
-                        full = ema99(full, xj);
-                        c = capped_step(c, xj, cap);
+                        full = ema99(full, xs[j]);
+                        c = capped_step(c, xs[j], cap);
                     }
                 }
             }
+            ++kk;
         }
     }
     if (lane == 0) {
         TpCore t;
         t.nf = nf, t.cap = cap, t.c = c, t.full = full;
         core[a.nseg] = t;
+        if (a.diag) {
+            a.diag[a.nrows * 4 + r * 4 + 0] = n_run;
+            a.diag[a.nrows * 4 + r * 4 + 1] = n_single;
+            a.diag[a.nrows * 4 + r * 4 + 2] = n_step;
+            a.diag[a.nrows * 4 + r * 4 + 3] = n_fail;
+        }
     }
 }
 
@@ -489,7 +587,7 @@ __global__ __launch_bounds__(64) void k_tp_scan(const TpArgs a) {
     float carryA = init.agc;
     bool all_ok = true;  // every segment so far accepted: carryE / carryA are the TRUE state
     uint32_t first_bad = a.nseg;
-    int sum_open = 0, sum_flappy = 0;
+    int sum_open = 0, sum_flappy = 0, nbad = 0;
 
     for (uint32_t g0 = 0; g0 < a.nseg; g0 += 64) {
         const uint32_t k = g0 + lane;
@@ -530,6 +628,7 @@ __global__ __launch_bounds__(64) void k_tp_scan(const TpArgs a) {
         const unsigned long long okmask = __ballot(ok);
         const unsigned long long havemask = __ballot(have);
         const unsigned long long bad = havemask & ~okmask;
+        nbad += __popcll(bad);
         if (all_ok) {
             // counters only over the accepted prefix
             const int nacc = bad ? __ffsll(static_cast<long long>(bad)) - 1 : __popcll(havemask);
@@ -563,6 +662,8 @@ __global__ __launch_bounds__(64) void k_tp_scan(const TpArgs a) {
         f.d_open = sum_open;
         f.d_flappy = sum_flappy;
         a.fin[r] = f;
+        if (a.diag)
+            a.diag[r * 4 + (a.scan_round & 3)] = nbad;
     }
 }
 
@@ -745,7 +846,8 @@ __global__ void k_tp_prologue(const TpArgs a) {
             return e__;                                           \
     } while (0)
 
-hipError_t launch_tp(const TpArgs& a, hipStream_t s) {
+hipError_t launch_tp(const TpArgs& a_in, hipStream_t s) {
+    TpArgs a = a_in;
     if (a.nrows == 0 || a.nsteps == 0)
         return hipSuccess;
     const int lanes1 = a.nrows * static_cast<int>((a.nsteps + TP_L1 - 1) / TP_L1);
@@ -755,11 +857,14 @@ hipError_t launch_tp(const TpArgs& a, hipStream_t s) {
     TP_LAUNCH(k_tp_core, a.nrows, 64);
     TP_LAUNCH(k_tp_seg, (lanes + 63) / 64, 64);
     for (int round = 0; round < 2; ++round) {
+        a.scan_round = round;
         TP_LAUNCH(k_tp_scan, a.nrows, 64);
         TP_LAUNCH(k_tp_fix, (lanes + 63) / 64, 64);
     }
+    a.scan_round = 2;
     TP_LAUNCH(k_tp_scan, a.nrows, 64);
     TP_LAUNCH(k_tp_fallback, (a.nrows + 63) / 64, 64);
+    a.scan_round = 3;
     TP_LAUNCH(k_tp_scan, a.nrows, 64);
     TP_LAUNCH(k_tp_fades, (lanes + 63) / 64, 64);
     TP_LAUNCH(k_tp_finish, a.nrows, 64);

@@ -144,6 +144,12 @@ int mi_demod_set_state(mi_demod* h, const void* buf, size_t len);
  * the tests can assert that.  Synchronises. */
 int mi_demod_last_path(mi_demod* h, int* time_parallel, int* unverified_rows);
 
+/* Diagnostics of the time-parallel path after a call that took it (synchronises): the exact Squelch core
+ * state {noise_floor_, moving_avg_cap_, pre_filter_.capped_, pre_filter_.full_} before each 512-step segment
+ * (core4: [nseg+1][4]) and diag8[0..3] = segments not accepted in verification scans 0..3 (scan 3 runs after the
+ * serial fallback and is always 0; diag4[2] != 0 means the fallback had to run). */
+int mi_demod_tp_debug(mi_demod* h, int row, float* core4, int max_entries, int* diag8, int* nseg);
+
 /* Diagnostic view of stage 1's output as stage 2 left it after the last call (synchronises): the
  * magnitude plane of (stream, ch), plane index 0 = the oldest carried sample; after a call of n steps
  * indices [0, AGC_EXTRA) hold the carry for the next call.  iq may be NULL; it is only filled for

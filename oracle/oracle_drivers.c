@@ -189,3 +189,25 @@ typedef struct {
     int32_t is_open, should_process_audio;
     uint64_t open_count, ctcss_count, no_ctcss_count;
 } ao_squelch_probe;
+
+/* exact (noise_floor_, moving_avg_cap_, pre_filter_.capped_, pre_filter_.full_) BEFORE raw sample k*stride,
+ * k = 0 .. n/stride, for checking the time-parallel core chain of the HIP path (tp.hip) */
+void ao_squelch_core_trace(const ao_squelch_cfg* cfg, const float* raw, size_t n, size_t stride, float* out4) {
+    ao_squelch sq;
+    ao_squelch_init(&sq);
+    if (cfg->manual_level > 0)
+        ao_squelch_set_level_threshold(&sq, cfg->manual_level);
+    if (cfg->has_snr)
+        ao_squelch_set_snr_threshold(&sq, cfg->snr_db);
+    for (size_t i = 0; i <= n; i++) {
+        if (i % stride == 0 || i == n) {
+            size_t k = (i == n && i % stride != 0) ? i / stride + 1 : i / stride;
+            out4[4 * k + 0] = sq.noise_floor;
+            out4[4 * k + 1] = sq.moving_avg_cap;
+            out4[4 * k + 2] = sq.pre_capped;
+            out4[4 * k + 3] = sq.pre_full;
+        }
+        if (i < n)
+            ao_squelch_process_raw(&sq, raw[i]);
+    }
+}

@@ -294,3 +294,40 @@ def test_time_parallel_hard_signals(pkg, monkeypatch):
     assert_same(axc[0], oaxc, "axcindicate")
     assert_same(wo[0], owo, "audio")
     assert max(s.flappy_count for s in st) > 0, "the input was meant to trigger flap detection"
+
+
+def test_time_parallel_core_chain_exact_and_no_fallback(pkg, monkeypatch):
+    """The exact Squelch core state (noise floor, cap, capped, full) the time-parallel path computes at every
+    512-step boundary equals the oracle's serial values, and the gated-carrier workload needs no serial
+    fallback: only the segments holding an opening edge are re-run (scan 0), then everything verifies."""
+    import ctypes as C
+    import libs
+    from common import to_oracle_cfg
+    monkeypatch.setenv("MI_AIRBAND_TP", "1")
+    centre, chans = pkg.config2_channels()
+    chans[1] = pkg.channel_cfg(chans[1].freq, squelch_threshold_dbfs=-30)  # manual level: constant cap
+    chans[3] = pkg.channel_cfg(chans[3].freq, squelch_snr_db=1.0)
+    dev = pkg.device_cfg(centerfreq=centre)
+    nbat = 96
+    iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=2, active=lambda k: k != 5)
+    odev, ochans = to_oracle_cfg(dev, chans)
+    od = libs.OracleDemod(odev, ochans)
+    omag, _ = od.stage1(iq, nbat * WAVE_BATCH + AGC_EXTRA, want_iq=False)
+    lib = libs.oracle_lib()
+    lib.ao_squelch_core_trace.argtypes = [C.POINTER(libs.SquelchCfg), libs.f32p, C.c_size_t, C.c_size_t, libs.f32p]
+    lib.ao_squelch_core_trace.restype = None
+    lib.ao_dbfs_to_level.restype = C.c_float
+    d = pkg.Demod(dev, chans, max_batches=nbat)
+    d.process([iq], nbat)
+    assert d.last_path() == (1, 0)
+    for c, ch in enumerate(chans):
+        core, diag = d.tp_debug(c)
+        n = nbat * WAVE_BATCH
+        ref = np.zeros(((n + 511) // 512 + 1, 4), np.float32)
+        manual = lib.ao_dbfs_to_level(C.c_float(ch.squelch_threshold_dbfs), 512) if ch.squelch_threshold_dbfs < 0 else 0.0
+        cfg = libs.SquelchCfg(manual, ch.has_snr_threshold, ch.squelch_snr_db, 0.0, 16000.0)
+        lib.ao_squelch_core_trace(C.byref(cfg), np.ascontiguousarray(omag[c, AGC_EXTRA:]), n, 512, ref.reshape(-1))
+        assert_same(core, ref, f"core chain ch{c}")
+        assert diag[2] == 0 and diag[3] == 0, f"ch{c}: serial fallback engaged, scans={diag.tolist()}"
+        assert diag[0] <= nbat // 8 + 2, f"ch{c}: unexpectedly many segments re-run: {diag.tolist()}"
+    d.close()
