@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--seconds", type=float, default=8.0, help="capture length per stream per step (HBM-resident)")
+    ap.add_argument("--seconds", type=float, default=64.0, help="capture length per stream per step (HBM-resident)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="length of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of audio to rank 0 (N>1)")
     args = ap.parse_args()
@@ -110,16 +110,15 @@ def main():
     # prime: the handle's first call consumes AGC_EXTRA extra windows (waveend starts at 0 in the reference)
     h.process_device(d_iq.data_ptr(), nbytes, nbat, d_wo.data_ptr(), d_axc.data_ptr(), hip_stream=stream.cuda_stream)
     base = d_iq.data_ptr() + AGC_EXTRA * hop
-    kms = [0.0, 0.0]
+    kms = {}
 
     def step(timed):
         h.process_device(base, nbytes - AGC_EXTRA * hop, nbat, d_wo.data_ptr(), d_axc.data_ptr(), hip_stream=stream.cuda_stream)
         if world > 1 and not args.no_gather:
             dist.gather(d_wo, gather_list, dst=0)
         if timed:
-            a, b = h.last_kernel_ms()  # HIP events around each kernel on the launch stream
-            kms[0] += a
-            kms[1] += b
+            for name, ms in h.kernel_times():  # HIP events between the launches, on the launch stream
+                kms[name] = kms.get(name, 0.0) + ms
 
     for _ in range(args.warmup):
         step(False)
@@ -145,18 +144,21 @@ def main():
     value = total_samples / dt / 1e6  # MS/s, whole job
 
     if rank == 0:
-        ch_ms, dm_ms = kms[0] / args.steps, kms[1] / args.steps
-        # algorithmic HBM bytes per complex input sample (DESIGN.md "Kernels"):
-        #   channelize: 2 B IQ read + 4*nch/160 B magnitudes written           (2.2 B/sample @ 8 ch)
-        #   demod     : 4*nch/160 B magnitudes read + 4*nch/160 B audio written
+        # algorithmic HBM bytes per complex input sample, per kernel (DESIGN.md "Kernels"); hop = 160 samples
         hopn = SAMPLE_RATE // 16000
-        bytes_ch = samples_per_step_per_gpu * (2.0 + 4.0 * nch / hopn)
-        bytes_dm = samples_per_step_per_gpu * (8.0 * nch / hopn)
-        kernels = {
-            "channelize": {"ms": ch_ms, "algorithmic_bytes": bytes_ch, "GBps": bytes_ch / (ch_ms * 1e-3) / 1e9 if ch_ms > 0 else None},
-            "demod": {"ms": dm_ms, "algorithmic_bytes": bytes_dm, "GBps": bytes_dm / (dm_ms * 1e-3) / 1e9 if dm_ms > 0 else None},
+        per_sample = {
+            "k_channelize": 2.0 + 4.0 * nch / hopn,    # u8 I+Q read once + |bin| written        (2.2 B/sample @ 8 ch)
+            "k_demod": 8.0 * nch / hopn,               # |bin| read + audio written
+            "k_tp_full": 5.0 * nch / hopn,             # |bin| read + 16 B of block aggregates per 16 steps
+            "k_tp_core": 5.0 * nch / hopn,             # aggregates + raw samples read
+            "k_tp_seg": 8.0 * nch / hopn,              # |bin| read + audio written
         }
-        dom = "channelize" if ch_ms >= dm_ms else "demod"
+        kernels = {}
+        for name, tot in kms.items():
+            ms = tot / args.steps
+            nbytes = samples_per_step_per_gpu * per_sample.get(name.split("#")[0], 0.0)
+            kernels[name] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": (nbytes / (ms * 1e-3) / 1e9) if ms > 0 and nbytes > 0 else None}
+        dom = max(kernels, key=lambda k: kernels[k]["ms"])
         achieved = kernels[dom]["GBps"]
         out = {
             "metric": "IQ MS/s processed (x real-time) @ 8ch fft_size=512",
@@ -173,7 +175,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 1 device stream per GPU @ 2.56 MS/s u8 IQ, 8 AM channels, fft_size=512",
                        "streams_per_gpu": 1, "channels": nch, "fft_size": 512, "capture_seconds_per_step": nbat / 8.0,
-                       "audio_gather_to_rank0": bool(world > 1 and not args.no_gather)},
+                       "audio_gather_to_rank0": bool(world > 1 and not args.no_gather),
+                       "stage2_path": "time-parallel" if h.last_path()[0] == 1 else "serial"},
             "x_realtime_per_stream": value / world / (SAMPLE_RATE / 1e6),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None},

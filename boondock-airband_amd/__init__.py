@@ -79,7 +79,7 @@ class IqGenCfg(C.Structure):
 ABI_SYMBOLS = [
     "mi_last_error", "mi_device_count", "mi_demod_create", "mi_demod_destroy", "mi_demod_bytes_needed", "mi_demod_bytes_consumed",
     "mi_demod_hop_bytes", "mi_demod_process", "mi_demod_process_device", "mi_demod_get_stats", "mi_demod_state_size",
-    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_tp_debug","mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
+    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_tp_debug", "mi_demod_kernel_time","mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
     "mi_plan_window", "mi_plan_twiddles", "mi_plan_levels", "mi_plan_sincos_lut", "mi_plan_channel", "mi_plan_ctcss_coeffs",
     "mi_iqgen_host", "mi_iqgen_device",
 ]
@@ -113,6 +113,7 @@ def lib():
         L.mi_demod_get_state.argtypes = [vp, vp, sz]
         L.mi_demod_set_state.argtypes = [vp, vp, sz]
         L.mi_demod_last_path.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mi_demod_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]
         L.mi_demod_tp_debug.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_int)]
         L.mi_demod_read_planes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.mi_demod_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -287,6 +288,18 @@ class Demod:
         _check(lib().mi_demod_read_planes(self._h, stream, ch, first, count, mag.ctypes.data_as(C.c_void_p),
                                           None if iq is None else iq.ctypes.data_as(C.c_void_p)))
         return mag, iq
+
+    def kernel_times(self):
+        """[(kernel name, ms)] of the last device-entry call, in launch order (HIP events on the launch stream)."""
+        out = []
+        i = 0
+        while True:
+            name, ms = C.c_char_p(), C.c_float(0)
+            if lib().mi_demod_kernel_time(self._h, i, C.byref(name), C.byref(ms)) != MI_OK:
+                break
+            out.append((name.value.decode(), ms.value))
+            i += 1
+        return out
 
     def last_kernel_ms(self):
         a, b = C.c_float(0), C.c_float(0)

@@ -129,7 +129,10 @@ struct TpArgs {
     TpFinal* fin;                              // [nrows]
     int* diag;                                 // [nrows][4]: segments not accepted in scan 0..3
     int scan_round;
+    hipEvent_t* kev;                           // TP_NKERN+1 events recorded between the launches, or null
 };
+constexpr int TP_NKERN = 13;
+extern const char* const kTpKernelNames[TP_NKERN];
 
 hipError_t launch_tp(const TpArgs& a, hipStream_t s);
 

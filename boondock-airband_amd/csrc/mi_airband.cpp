@@ -59,6 +59,7 @@ struct mi_demod {
     size_t plane_stride = 0;
     hipStream_t own_stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t tpev[mi::TP_NKERN + 1] = {};
     bool ev_valid = false;
     // device memory
     float* d_window = nullptr;
@@ -211,6 +212,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.need = h->d_need;
         ta.fin = h->d_fin;
         ta.diag = h->d_diag;
+        ta.kev = h->tpev;
         h->last_nseg = ta.nseg;
         HIP_TRY(mi::launch_tp(ta, s));
     } else {
@@ -251,6 +253,9 @@ void mi_demod_destroy(mi_demod* h) {
     if (h->h_pin)
         (void)hipHostFree(h->h_pin);
     for (hipEvent_t e : h->ev)
+        if (e)
+            (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->tpev)
         if (e)
             (void)hipEventDestroy(e);
     if (h->own_stream)
@@ -310,6 +315,8 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     TRY_OR_BAIL(hipSetDevice(gpu));
     TRY_OR_BAIL(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     for (auto& ev : h->ev)
+        TRY_OR_BAIL(hipEventCreate(&ev));
+    for (auto& ev : h->tpev)
         TRY_OR_BAIL(hipEventCreate(&ev));
     const size_t rows = static_cast<size_t>(h->rows);
     TRY_OR_BAIL(dalloc(&h->d_window, p.window.size()));
@@ -594,6 +601,34 @@ int mi_demod_read_planes(mi_demod* h, int stream, int ch, int first, int count, 
         const size_t zrow = static_cast<size_t>(stream) * h->plan.n_iq_rows + iq_row;
         HIP_TRY(hipMemcpy(iq, h->d_cplx + zrow * h->plane_stride + first, static_cast<size_t>(count) * 8, hipMemcpyDeviceToHost));
     }
+    return MI_OK;
+}
+
+int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms) {
+    if (!h || !h->ev_valid || index < 0)
+        return fail(MI_ERR_INVALID, "no call has been timed yet");
+    HIP_TRY(hipSetDevice(h->gpu));
+    HIP_TRY(hipEventSynchronize(h->ev[2]));
+    float t = 0.f;
+    const char* nm = nullptr;
+    if (index == 0) {
+        nm = "k_channelize";
+        HIP_TRY(hipEventElapsedTime(&t, h->ev[0], h->ev[1]));
+    } else if (h->last_path == 0) {
+        if (index != 1)
+            return fail(MI_ERR_INVALID, "kernel index out of range");
+        nm = "k_demod";
+        HIP_TRY(hipEventElapsedTime(&t, h->ev[1], h->ev[2]));
+    } else {
+        if (index > mi::TP_NKERN)
+            return fail(MI_ERR_INVALID, "kernel index out of range");
+        nm = mi::kTpKernelNames[index - 1];
+        HIP_TRY(hipEventElapsedTime(&t, h->tpev[index - 1], h->tpev[index]));
+    }
+    if (name)
+        *name = nm;
+    if (ms)
+        *ms = t;
     return MI_OK;
 }
 

@@ -846,28 +846,52 @@ __global__ void k_tp_prologue(const TpArgs a) {
             return e__;                                           \
     } while (0)
 
+const char* const kTpKernelNames[TP_NKERN] = {"k_tp_prologue", "k_tp_full", "k_tp_core",  "k_tp_seg",      "k_tp_scan#0", "k_tp_fix#0", "k_tp_scan#1",
+                                              "k_tp_fix#1",    "k_tp_scan#2", "k_tp_fallback", "k_tp_scan#3", "k_tp_fades", "k_tp_finish"};
+
+#define TP_MARK(i)                                        \
+    do {                                                  \
+        if (a.kev) {                                      \
+            hipError_t e__ = hipEventRecord(a.kev[i], s); \
+            if (e__ != hipSuccess)                        \
+                return e__;                               \
+        }                                                 \
+    } while (0)
+
 hipError_t launch_tp(const TpArgs& a_in, hipStream_t s) {
     TpArgs a = a_in;
     if (a.nrows == 0 || a.nsteps == 0)
         return hipSuccess;
     const int lanes1 = a.nrows * static_cast<int>((a.nsteps + TP_L1 - 1) / TP_L1);
     const int lanes = a.nrows * static_cast<int>(a.nseg);
+    TP_MARK(0);
     TP_LAUNCH(k_tp_prologue, (a.nrows * kAgcExtra + 255) / 256, 256);
+    TP_MARK(1);
     TP_LAUNCH(k_tp_full, (lanes1 + 63) / 64, 64);
+    TP_MARK(2);
     TP_LAUNCH(k_tp_core, a.nrows, 64);
+    TP_MARK(3);
     TP_LAUNCH(k_tp_seg, (lanes + 63) / 64, 64);
     for (int round = 0; round < 2; ++round) {
         a.scan_round = round;
+        TP_MARK(4 + 2 * round);
         TP_LAUNCH(k_tp_scan, a.nrows, 64);
+        TP_MARK(5 + 2 * round);
         TP_LAUNCH(k_tp_fix, (lanes + 63) / 64, 64);
     }
     a.scan_round = 2;
+    TP_MARK(8);
     TP_LAUNCH(k_tp_scan, a.nrows, 64);
+    TP_MARK(9);
     TP_LAUNCH(k_tp_fallback, (a.nrows + 63) / 64, 64);
     a.scan_round = 3;
+    TP_MARK(10);
     TP_LAUNCH(k_tp_scan, a.nrows, 64);
+    TP_MARK(11);
     TP_LAUNCH(k_tp_fades, (lanes + 63) / 64, 64);
+    TP_MARK(12);
     TP_LAUNCH(k_tp_finish, a.nrows, 64);
+    TP_MARK(13);
     return hipSuccess;
 }
 
