@@ -1,0 +1,134 @@
+// airband_replay -- replays a raw IQ capture through the host mirror: file feed -> input_t ring
+// (circbuffer_append, as input-file.cpp:82-147 does) -> demodulate() thread (engine on the GPU) ->
+// output thread role (output.cpp:933-950) -> one raw f32 file per channel + the axcindicate flags.
+//
+// Deterministic drive: the feeder hands over less than one batch at a time and waits until the demod
+// thread has starved and the output side has drained, so no batch is ever overrun and EOF drops nothing.
+//
+// usage: airband_replay <config.txt> <capture.iq> <out_prefix> [gpu]
+//   config.txt: line 1 "sample_rate centerfreq fft_size_log sfmt tau fm_quadri"
+//               then per channel "freq modulation squelch_threshold_dbfs has_snr snr_db notch notch_q ctcss bandwidth ampfactor tau afc has_iq"
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "airband_host.hpp"
+
+struct Sink {
+    std::vector<FILE*> audio;
+    std::vector<std::string> flags;
+    size_t batches = 0;
+};
+
+static void sink_fn(void* user, int /*device*/, int channel, const float* waveout, const float* /*iq_out*/, char axc) {
+    Sink* s = (Sink*)user;
+    fwrite(waveout, sizeof(float), WAVE_BATCH, s->audio[(size_t)channel]);
+    s->flags[(size_t)channel].push_back(axc);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) {
+        fprintf(stderr, "usage: %s <config.txt> <capture.iq> <out_prefix> [gpu]\n", argv[0]);
+        return 2;
+    }
+    const int gpu = argc > 4 ? atoi(argv[4]) : 0;
+    FILE* cf = fopen(argv[1], "r");
+    if (!cf) {
+        perror("config");
+        return 2;
+    }
+    int sample_rate, centerfreq, fftlog, sfmt, tau, quadri;
+    if (fscanf(cf, "%d %d %d %d %d %d", &sample_rate, &centerfreq, &fftlog, &sfmt, &tau, &quadri) != 6) {
+        fprintf(stderr, "bad device line\n");
+        return 2;
+    }
+    std::vector<mi_channel_cfg> chans;
+    while (true) {
+        mi_channel_cfg c;
+        int n = fscanf(cf, "%d %d %d %d %f %f %f %f %d %f %d %d %d", &c.freq, &c.modulation, &c.squelch_threshold_dbfs, &c.has_snr_threshold,
+                       &c.squelch_snr_db, &c.notch_freq, &c.notch_q, &c.ctcss_freq, &c.bandwidth, &c.ampfactor, &c.tau, &c.afc, &c.has_iq_outputs);
+        if (n != 13)
+            break;
+        chans.push_back(c);
+    }
+    fclose(cf);
+    if (chans.empty()) {
+        fprintf(stderr, "no channels\n");
+        return 2;
+    }
+    fft_size_log = (size_t)fftlog;
+    fft_size = (size_t)1 << fftlog;
+    fm_quadri_demod_selected = quadri;
+
+    input_t* in = input_new_for_format((sample_format_t)sfmt, sample_rate, centerfreq);
+    device_t* dev = device_new(in, chans.data(), (int)chans.size(), tau);
+    devices = dev;
+    device_count = 1;
+    devices_running = 1;
+    Signal sig;
+    demod_params_t dp;
+    if (init_demod(&dp, &sig, 0, 1, gpu) != 0)
+        return 1;  // the reference calls error() here (rtl_airband.cpp:318-332)
+
+    Sink sink;
+    for (size_t i = 0; i < chans.size(); i++) {
+        std::string p = std::string(argv[3]) + "_ch" + std::to_string(i) + ".f32";
+        sink.audio.push_back(fopen(p.c_str(), "wb"));
+        sink.flags.emplace_back();
+    }
+    FILE* iq = fopen(argv[2], "rb");
+    if (!iq) {
+        perror("capture");
+        return 2;
+    }
+    in->state = INPUT_RUNNING;
+    pthread_t th;
+    pthread_create(&th, NULL, &demodulate, &dp);
+
+    const size_t hop = mi_demod_hop_bytes(dev->engine);
+    std::vector<unsigned char> chunk(hop * 1000);  // < one batch
+    auto starved = [&]() {
+        pthread_mutex_lock(&in->buffer_lock);
+        size_t avail = in->bufe >= in->bufs ? in->bufe - in->bufs : in->buf_size - in->bufs + in->bufe;
+        pthread_mutex_unlock(&in->buffer_lock);
+        return avail < mi_demod_bytes_consumed(dev->engine, 1) + fft_size * (size_t)in->bytes_per_sample * 2;
+    };
+    auto settle = [&]() {  // wait until the demod thread cannot run and the output side has consumed what it produced
+        for (int spin = 0; spin < 200000; spin++) {
+            if (output_consume(dev, 0, &sink_fn, &sink))
+                sink.batches++;
+            if (starved() && !dev->waveavail) {
+                usleep(2000);  // the demod thread may be between its availability check and the engine call
+                if (starved() && !dev->waveavail)
+                    return;
+            }
+            usleep(200);
+        }
+    };
+    while (true) {
+        size_t len = fread(chunk.data(), 1, chunk.size(), iq);
+        if (len == 0)
+            break;
+        circbuffer_append(in, chunk.data(), len);
+        settle();
+    }
+    settle();
+    do_exit = 1;
+    pthread_join(th, NULL);
+    fclose(iq);
+    for (FILE* f : sink.audio)
+        fclose(f);
+    std::string fp = std::string(argv[3]) + "_axc.txt";
+    FILE* ff = fopen(fp.c_str(), "w");
+    for (const std::string& s : sink.flags)
+        fprintf(ff, "%s\n", s.c_str());
+    fclose(ff);
+    printf("batches=%zu overruns=%zu overflows=%zu\n", sink.batches, dev->output_overrun_count, in->overflow_count);
+    device_free(dev);
+    input_free(in);
+    return 0;
+}
