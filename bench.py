@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=64.0, help="capture length per stream per step (HBM-resident)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="length of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--noise-only", action="store_true", help="diagnostic: no carriers in the synthetic capture (squelch never opens)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of audio to rank 0 (N>1)")
     args = ap.parse_args()
 
@@ -97,7 +98,7 @@ def main():
     stream = torch.cuda.current_stream()
 
     # synthetic capture of this rank's stream, generated on the device (same integer recipe as the host generator)
-    gcfg = pkg.iqgen_cfg(sample_rate=SAMPLE_RATE, gate_samples=SAMPLE_RATE, carriers=pkg.carriers_for(centre, chans))
+    gcfg = pkg.iqgen_cfg(sample_rate=SAMPLE_RATE, gate_samples=SAMPLE_RATE, carriers=() if args.noise_only else pkg.carriers_for(centre, chans))
     d_iq = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     pkg.iqgen_device(gcfg, rank, 1, nbytes, 0, nbytes // 2, d_iq.data_ptr(), stream.cuda_stream)
     d_wo = torch.empty((1, nch, nsteps), dtype=torch.float32, device="cuda")

@@ -137,6 +137,11 @@ __device__ __forceinline__ float wl(const float vec, const float val, const int 
     return (static_cast<int>(threadIdx.x) == lane) ? val : vec;  // v_cmp + v_cndmask with a scalar lane index
 }
 
+// lane j <- lane j-1, lane 0 <- `first` (DPP wave_shr:1, all lanes take part: call it from uniform control flow only)
+__device__ __forceinline__ float wave_shr1(const float v, const float first) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+
 struct CoreGroup {  // what lane l holds for block g0 + l
     float fe, fm, x0, xm;
     float4 s0, s1, s2, s3;  // the block's 16 raw samples (only read when the block has to be stepped)
@@ -179,10 +184,12 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
 
     int n_run = 0, n_single = 0, n_step = 0, n_fail = 0;  // diagnostics: blocks per path, failed hypotheses
     CoreGroup nxt = core_load(a, x, bbase, 0, lane);
+    CoreGroup nxt2 = core_load(a, x, bbase, 64, lane);
     for (uint32_t g0 = 0; g0 < nblk; g0 += 64) {
         const CoreGroup cur = nxt;
-        if (g0 + 64 < nblk)
-            nxt = core_load(a, x, bbase, g0 + 64, lane);  // in flight while this group is walked
+        nxt = nxt2;
+        if (g0 + 128 < nblk)
+            nxt2 = core_load(a, x, bbase, g0 + 128, lane);  // two groups in flight while this one is walked
         const int nb = static_cast<int>(min(64u, nblk - g0));
         const float fe_prev = __shfl_up(cur.fe, 1);  // full_ at the start of lane's block, valid for lane > kk
         const bool boundary = ((g0 + lane) % bps) == 0;
@@ -192,26 +199,27 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                 // Hypothesis: the regime of the current block persists.  The noise-floor chain is walked serially
                 // (the only true dependence), every block's precondition is then checked by its own lane.
                 const bool merged = (c == full);
-                float vnf = 0.0f, vprev = 0.0f;  // lane j: noise floor after / before block j's update
+                // Systolic evaluation: lane j holds "noise floor after block j"; every pass shifts the vector one lane up
+                // (v_mov_dpp wave_shr:1), applies the update with the lane's own operand and keeps lanes below kk at
+                // the current state.  After pass t lanes kk .. kk+t-1 are final; nb-kk passes settle the whole group.
+                // No scalar loop-carried value, no lane writes: ~8 VALU per block on the serial chain.
+                const bool upd = lane >= kk;
+                float vnf = nf;
                 if (merged) {
-                    float nfc = nf, cc = c;
-                    for (int j = kk; j < nb; ++j) {
-                        vprev = wl(vprev, nfc, j);
-                        nfc = noise_floor_step(nfc, cc);
-                        vnf = wl(vnf, nfc, j);
-                        cc = rl(cur.fe, j);  // capped_ == full_ at the end of block j under the hypothesis
+                    const float cen = (lane == kk) ? c : fe_prev;  // capped_ (== full_) entering the lane's block
+                    for (int it = kk; it < nb; ++it) {
+                        const float prev = wave_shr1(vnf, nf);
+                        const float nv = noise_floor_step(prev, cen);
+                        vnf = upd ? nv : vnf;
                     }
                 } else {
-                    float nfc = nf, cc = c;
-                    for (int j = kk; j < nb; ++j) {
-                        vprev = wl(vprev, nfc, j);
-                        nfc = noise_floor_step(nfc, cc);
-                        vnf = wl(vnf, nfc, j);
-                        cc = cap_of(p, nfc);  // capped_ == cap at the end of block j under the hypothesis
+                    for (int it = kk; it < nb; ++it) {
+                        const float prev = wave_shr1(vnf, nf);
+                        const float nv = noise_floor_step(prev, cap_of(p, prev));  // capped_ == cap entering the block
+                        vnf = upd ? nv : vnf;
                     }
                 }
-                // (no cross-lane read here: a shuffle sunk under `lane != kk` would see lane kk inactive and return 0)
-                const float nf_prev = vprev;
+                const float nf_prev = wave_shr1(vnf, nf);  // lanes <= kk read the current state
                 const float cap_prev = (lane == kk) ? cap : cap_of(p, nf_prev);
                 const float capj = cap_of(p, vnf);
                 const float full_entry = (lane == kk) ? full : fe_prev;
@@ -235,6 +243,7 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                     c = merged ? full : cap;
                     kk += nacc;
                     n_run += nacc;
+                    ++n_single;  // (diagnostic slot reused: number of accepted runs)
                     continue;
                 }
                 ++n_fail;
@@ -254,11 +263,9 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
             if (valid && c == full && c < cap && fm < cap) {  // MERGED
                 c = fe;
                 full = fe;
-                ++n_single;
             } else if (valid && capped_step(c, x0, cap) == cap && xm >= cap) {  // SATURATED
                 c = cap;
                 full = fe;
-                ++n_single;
             } else {  // STEP: the 16 samples one by one
                 ++n_step;
                 const float xs[16] = {rl(cur.s0.x, kk), rl(cur.s0.y, kk), rl(cur.s0.z, kk), rl(cur.s0.w, kk), rl(cur.s1.x, kk), rl(cur.s1.y, kk),
@@ -461,28 +468,130 @@ __device__ __forceinline__ void out_store4(const TpArgs& a, const int row, const
         *reinterpret_cast<float4*>(a.carry + static_cast<size_t>(row) * kAgcExtra + (vi - a.nsteps)) = v;
 }
 
-// run steps [i0, i1) (multiples of 4); writes audio when in_seg
+// four steps i .. i+3 (i a multiple of 4) from the chunk's squelch samples xc and audio samples ac
+//
+// Fast paths: in the steady and the waiting regimes of the state machine nothing but counters moves, which is
+// proven for the whole chunk on a trial copy of the core state before anything is committed:
+//   CLOSED/CLOSED    no sample reaches the squelch level          -> closed_sample_count_ (+ the flap reset), audio 0
+//   OPEN/OPEN        capped_ stays >= level, low-signal count < 88 -> AGC + audio
+//   OPENING/OPENING  delay_ does not run out, low count < 88       -> delay_ += 4, audio 0
+//   CLOSING/CLOSING  delay_ does not run out, low count < 88       -> delay_ += 4, AGC + audio (still open)
+//   LSA/LSA          delay_ does not run out                       -> delay_ += 4, audio 0
+// Every other chunk (an edge, a delay running out, ...) takes tp_step() four times from the untouched state.
+__device__ __forceinline__ void tp_chunk(TpLane& s, const ChanParams& p, const TpArgs& a, const int row, const float* __restrict__ magrow,
+                                         const uint32_t i, const float4 xc, const float4 ac, const bool in_seg, const uint32_t batch0,
+                                         int* __restrict__ ev_slot, const size_t ev_stride) {
+    const float xv[4] = {xc.x, xc.y, xc.z, xc.w};
+    const float av[4] = {ac.x, ac.y, ac.z, ac.w};
+    float t_nf = s.nf, t_cap = s.cap, t_c = s.c, t_full = s.full, t_level = s.level;
+    if ((i & 15u) == 0) {  // i is a multiple of 4: only the chunk's first step can start a 16-sample block
+        t_nf = noise_floor_step(t_nf, t_c);
+        t_cap = cap_of(p, t_nf);
+        t_level = level_of(p, t_nf, s.recent);
+    }
+    bool all_below = true, all_above = true;
+    int low = s.low, lowmax = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        t_full = ema99(t_full, xv[k]);
+        t_c = capped_step(t_c, xv[k], t_cap);
+        all_below = all_below && !(t_c >= t_level);
+        all_above = all_above && (t_c >= t_level);
+        low = (xv[k] >= t_level) ? 0 : low + 1;  // squelch.cpp:236-244
+        lowmax = max(lowmax, low);
+    }
+    const bool same_state = s.cur == s.next;
+    const bool low_ok = lowmax < kLowSignalAbort;
+    const bool quiet = same_state && s.cur == SQ_CLOSED && all_below;
+    const bool steady_open = same_state && s.cur == SQ_OPEN && all_above && low_ok;
+    const bool wait_opening = same_state && s.cur == SQ_OPENING && s.delay + 4 < kOpenDelay && low_ok;
+    const bool wait_closing = same_state && s.cur == SQ_CLOSING && s.delay + 4 < kCloseDelay && low_ok;
+    const bool wait_lsa = same_state && s.cur == SQ_LSA && s.delay + 4 < kCloseDelay;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (quiet || steady_open || wait_opening || wait_closing || wait_lsa) {
+        s.nf = t_nf, s.cap = t_cap, s.c = t_c, s.full = t_full, s.level = t_level;
+        if (quiet) {
+            // squelch.cpp:442-449 four times; the reset fires at a step that starts with the count at 1000.  It only
+            // raises the level (normal >= flappy ratio), so the chunk stays quiet under the new level as well.
+            if (s.closed + 3 >= kRecent && s.recent != 0) {
+                s.recent = 0;
+                s.level = level_of(p, s.nf, 0);
+            }
+            s.closed = min(s.closed + 4, kRecent);
+        } else if (wait_lsa) {
+            s.delay += 4;
+        } else {
+            s.low = low;
+            if (!steady_open)
+                s.delay += 4;
+            if (!wait_opening) {  // OPEN or CLOSING: rtl_airband.cpp:574-641 with is_open() true
+                float wv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (xv[k] > t_level)
+                        s.agc = s.agc * 0.995f + xv[k] * 0.005f;
+                    float wout = (av[k] - s.agc) / (s.agc * 1.5f);
+                    if (fabsf(wout) > 0.8f) {
+                        wout *= 0.85f;
+                        s.agc *= 1.15f;
+                    }
+                    wout *= p.ampfactor;
+                    if (wout != wout)
+                        wout = 0.0f;
+                    else if (wout > 1.0f)
+                        wout = 1.0f;
+                    else if (wout < -1.0f)
+                        wout = -1.0f;
+                    wv[k] = wout;
+                    if (in_seg)
+                        s.open_mask |= (((i + k) / kWaveBatch) == batch0) ? 1 : 2;
+                }
+                if (in_seg)
+                    s.uses_agc = 1;
+                w = make_float4(wv[0], wv[1], wv[2], wv[3]);
+            }
+        }
+    } else {
+        // general path (rare): one copy of the full step, samples re-read from the (L1-resident) plane
+        float wv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const float wk = tp_step(s, p, i + k, magrow[kAgcExtra + i + k], magrow[i + k], magrow, in_seg, batch0, ev_slot, ev_stride);
+            wv[0] = (k == 0) ? wk : wv[0];
+            wv[1] = (k == 1) ? wk : wv[1];
+            wv[2] = (k == 2) ? wk : wv[2];
+            wv[3] = (k == 3) ? wk : wv[3];
+        }
+        w = make_float4(wv[0], wv[1], wv[2], wv[3]);
+    }
+    if (in_seg)
+        out_store4(a, row, i, w);
+}
+
+// run steps [i0, i1) (multiples of 16); writes audio when in_seg.  Sixteen steps of input per lane are requested
+// while the previous sixteen are processed.
 __device__ __forceinline__ void tp_run(TpLane& s, const ChanParams& p, const TpArgs& a, const int row, const float* __restrict__ magrow,
                                        const uint32_t i0, const uint32_t i1, const bool in_seg, const uint32_t batch0, const size_t rec_idx) {
     if (i0 >= i1)
         return;
     int* __restrict__ ev_slot = a.rec + 19 * a.rec_stride + rec_idx;
     const size_t ev_stride = a.rec_stride;
-    float4 xs = *reinterpret_cast<const float4*>(magrow + kAgcExtra + i0);
-    float4 as = *reinterpret_cast<const float4*>(magrow + i0);
-    for (uint32_t i = i0; i < i1; i += 4) {
-        const float4 xc = xs, ac = as;
-        if (i + 4 < i1) {  // next chunk in flight while this one is stepped
-            xs = *reinterpret_cast<const float4*>(magrow + kAgcExtra + i + 4);
-            as = *reinterpret_cast<const float4*>(magrow + i + 4);
+    const float4* __restrict__ xp = reinterpret_cast<const float4*>(magrow + kAgcExtra);
+    const float4* __restrict__ ap = reinterpret_cast<const float4*>(magrow);
+    uint32_t q = i0 >> 2;
+    float4 x0 = xp[q], x1 = xp[q + 1], x2 = xp[q + 2], x3 = xp[q + 3];
+    float4 a0 = ap[q], a1 = ap[q + 1], a2 = ap[q + 2], a3 = ap[q + 3];
+    for (uint32_t i = i0; i < i1; i += 16) {
+        const float4 cx0 = x0, cx1 = x1, cx2 = x2, cx3 = x3, ca0 = a0, ca1 = a1, ca2 = a2, ca3 = a3;
+        if (i + 16 < i1) {
+            q = (i + 16) >> 2;
+            x0 = xp[q], x1 = xp[q + 1], x2 = xp[q + 2], x3 = xp[q + 3];
+            a0 = ap[q], a1 = ap[q + 1], a2 = ap[q + 2], a3 = ap[q + 3];
         }
-        float4 w;
-        w.x = tp_step(s, p, i, xc.x, ac.x, magrow, in_seg, batch0, ev_slot, ev_stride);
-        w.y = tp_step(s, p, i + 1, xc.y, ac.y, magrow, in_seg, batch0, ev_slot, ev_stride);
-        w.z = tp_step(s, p, i + 2, xc.z, ac.z, magrow, in_seg, batch0, ev_slot, ev_stride);
-        w.w = tp_step(s, p, i + 3, xc.w, ac.w, magrow, in_seg, batch0, ev_slot, ev_stride);
-        if (in_seg)
-            out_store4(a, row, i, w);
+        tp_chunk(s, p, a, row, magrow, i, cx0, ca0, in_seg, batch0, ev_slot, ev_stride);
+        tp_chunk(s, p, a, row, magrow, i + 4, cx1, ca1, in_seg, batch0, ev_slot, ev_stride);
+        tp_chunk(s, p, a, row, magrow, i + 8, cx2, ca2, in_seg, batch0, ev_slot, ev_stride);
+        tp_chunk(s, p, a, row, magrow, i + 12, cx3, ca3, in_seg, batch0, ev_slot, ev_stride);
     }
 }
 
