@@ -58,7 +58,8 @@ __device__ __forceinline__ float capped_step(const float c, const float x, const
 }
 __device__ __forceinline__ float noise_floor_step(const float nf, const float c) {
     const float nfac = static_cast<float>(1.0 - static_cast<double>(0.97f));
-    const float m = (nf < c) ? nf : c;  // std::min(capped, noise_floor)
+    // std::min(capped, noise_floor); both are finite and > 0 here, so v_min_f32 returns the same bits as the ternary
+    const float m = __builtin_fminf(c, nf);
     return nf * 0.97f + m * nfac + 1e-6f;
 }
 __device__ __forceinline__ float cap_of(const ChanParams& p, const float nf) {
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
     constexpr uint32_t bps = TP_L / 16;  // blocks per segment
 
     int n_run = 0, n_single = 0, n_step = 0, n_fail = 0;  // diagnostics: blocks per path, failed hypotheses
+    long long t_loop = 0, t_step = 0, t_all = clock64();
     CoreGroup nxt = core_load(a, x, bbase, 0, lane);
     CoreGroup nxt2 = core_load(a, x, bbase, 64, lane);
     for (uint32_t g0 = 0; g0 < nblk; g0 += 64) {
@@ -205,21 +207,37 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                 // No scalar loop-carried value, no lane writes: ~8 VALU per block on the serial chain.
                 const bool upd = lane >= kk;
                 float vnf = nf;
+                const long long tl0 = clock64();
                 if (merged) {
                     const float cen = (lane == kk) ? c : fe_prev;  // capped_ (== full_) entering the lane's block
-                    for (int it = kk; it < nb; ++it) {
-                        const float prev = wave_shr1(vnf, nf);
-                        const float nv = noise_floor_step(prev, cen);
-                        vnf = upd ? nv : vnf;
+                    if (kk == 0) {  // the common case, a whole group: every lane updates
+#pragma unroll 4
+                        for (int it = 0; it < nb; ++it)
+                            vnf = noise_floor_step(wave_shr1(vnf, nf), cen);
+                    } else {
+                        for (int it = kk; it < nb; ++it) {
+                            const float prev = wave_shr1(vnf, nf);
+                            const float nv = noise_floor_step(prev, cen);
+                            vnf = upd ? nv : vnf;
+                        }
                     }
                 } else {
-                    for (int it = kk; it < nb; ++it) {
-                        const float prev = wave_shr1(vnf, nf);
-                        const float nv = noise_floor_step(prev, cap_of(p, prev));  // capped_ == cap entering the block
-                        vnf = upd ? nv : vnf;
+                    if (kk == 0) {
+#pragma unroll 4
+                        for (int it = 0; it < nb; ++it) {
+                            const float prev = wave_shr1(vnf, nf);
+                            vnf = noise_floor_step(prev, cap_of(p, prev));  // capped_ == cap entering the block
+                        }
+                    } else {
+                        for (int it = kk; it < nb; ++it) {
+                            const float prev = wave_shr1(vnf, nf);
+                            const float nv = noise_floor_step(prev, cap_of(p, prev));
+                            vnf = upd ? nv : vnf;
+                        }
                     }
                 }
                 const float nf_prev = wave_shr1(vnf, nf);  // lanes <= kk read the current state
+                t_loop += clock64() - tl0;
                 const float cap_prev = (lane == kk) ? cap : cap_of(p, nf_prev);
                 const float capj = cap_of(p, vnf);
                 const float full_entry = (lane == kk) ? full : fe_prev;
@@ -268,13 +286,38 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                 full = fe;
             } else {  // STEP: the 16 samples one by one
                 ++n_step;
+                const long long ts0 = clock64();
                 const float xs[16] = {rl(cur.s0.x, kk), rl(cur.s0.y, kk), rl(cur.s0.z, kk), rl(cur.s0.w, kk), rl(cur.s1.x, kk), rl(cur.s1.y, kk),
                                       rl(cur.s1.z, kk), rl(cur.s1.w, kk), rl(cur.s2.x, kk), rl(cur.s2.y, kk), rl(cur.s2.z, kk), rl(cur.s2.w, kk),
                                       rl(cur.s3.x, kk), rl(cur.s3.y, kk), rl(cur.s3.z, kk), rl(cur.s3.w, kk)};
-                if (valid) {  // full_ at the block end is already known exactly
+                if (valid) {  // full_ at the block end is already known exactly: only the capped_ chain is serial
+                    // capped_step() with everything that does not depend on c hoisted off the chain: y = x*b, and the
+                    // shortcut "c >= cap && x >= cap" as "c >= t" with t = cap where x >= cap, +inf elsewhere.
+                    const float nfac = static_cast<float>(1.0 - static_cast<double>(0.99f));
+                    float ys[16], ts[16];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        c = capped_step(c, xs[j], cap);
+                    for (int j = 0; j < 16; ++j) {
+                        ys[j] = xs[j] * nfac;
+                        ts[j] = (xs[j] >= cap) ? cap : __int_as_float(0x7f800000);
+                    }
+                    // Trial: the cap does not bind anywhere in the block (the decay after a burst).  Then capped_ is the
+                    // bare EMA, two dependent operations per sample; accepted iff every value stayed below the cap.
+                    float cs = c, emax = c;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        cs = cs * 0.99f + ys[j];
+                        emax = fmaxf(emax, cs);
+                    }
+                    if (emax < cap) {
+                        c = cs;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const float e = c * 0.99f + ys[j];
+                            const float m = (e < cap) ? e : cap;
+                            c = (c >= ts[j]) ? cap : m;
+                        }
+                    }
                     full = fe;
                 } else {
 #pragma unroll
@@ -283,6 +326,7 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                         c = capped_step(c, xs[j], cap);
                     }
                 }
+                t_step += clock64() - ts0;
             }
             ++kk;
         }
@@ -292,10 +336,10 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
         t.nf = nf, t.cap = cap, t.c = c, t.full = full;
         core[a.nseg] = t;
         if (a.diag) {
-            a.diag[a.nrows * 4 + r * 4 + 0] = n_run;
-            a.diag[a.nrows * 4 + r * 4 + 1] = n_single;
-            a.diag[a.nrows * 4 + r * 4 + 2] = n_step;
-            a.diag[a.nrows * 4 + r * 4 + 3] = n_fail;
+            a.diag[a.nrows * 4 + r * 4 + 0] = n_run + 0 * n_single;
+            a.diag[a.nrows * 4 + r * 4 + 1] = static_cast<int>(t_loop >> 4);
+            a.diag[a.nrows * 4 + r * 4 + 2] = static_cast<int>(t_step >> 4);
+            a.diag[a.nrows * 4 + r * 4 + 3] = static_cast<int>((clock64() - t_all) >> 4) + 0 * (n_step + n_fail);
         }
     }
 }
