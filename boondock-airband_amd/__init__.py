@@ -113,7 +113,7 @@ def lib():
         L.mi_demod_get_state.argtypes = [vp, vp, sz]
         L.mi_demod_set_state.argtypes = [vp, vp, sz]
         L.mi_demod_last_path.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        L.mi_demod_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]
+        L.mi_demod_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.mi_demod_tp_debug.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_int)]
         L.mi_demod_read_planes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.mi_demod_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -290,14 +290,14 @@ class Demod:
         return mag, iq
 
     def kernel_times(self):
-        """[(kernel name, ms)] of the last device-entry call, in launch order (HIP events on the launch stream)."""
+        """[(kernel name, total ms, launches)] of the last call (HIP events on the launch streams)."""
         out = []
         i = 0
         while True:
-            name, ms = C.c_char_p(), C.c_float(0)
-            if lib().mi_demod_kernel_time(self._h, i, C.byref(name), C.byref(ms)) != MI_OK:
+            name, ms, n = C.c_char_p(), C.c_float(0), C.c_int(0)
+            if lib().mi_demod_kernel_time(self._h, i, C.byref(name), C.byref(ms), C.byref(n)) != MI_OK:
                 break
-            out.append((name.value.decode(), ms.value))
+            out.append((name.value.decode(), ms.value, n.value))
             i += 1
         return out
 

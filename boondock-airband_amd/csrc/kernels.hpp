@@ -109,7 +109,11 @@ struct TpFinal {
 struct TpArgs {
     const int* rows;  // handle rows (stream*nch + ch) taking this path
     int nrows, nch;
-    uint32_t nsteps, nbatches, nblk, nseg;
+    uint32_t nsteps, nbatches, nblk, nseg;  // totals of the call (array strides)
+    // The call is processed in chunks (multiples of lcm(TP_L, WAVE_BATCH) = 64000 steps) so that the serial core
+    // chain of chunk i+1 overlaps the parallel passes of chunk i on another HIP stream.  Absolute ranges:
+    uint32_t step0, step1, seg0, seg1, blk0, blk1, bat0, bat1;
+    int first_chunk, last_chunk;
     float* mag;
     size_t plane_stride;
     float* wmain;
@@ -119,22 +123,27 @@ struct TpArgs {
     const ChanParams* cp;
     ChanState* st;
     mi_channel_stats* stats;
-    const unsigned* xmax;  // [handle rows] bit pattern of the largest magnitude stage 1 wrote this call
+    const unsigned* xmax;  // [handle rows] bit pattern of the largest magnitude stage 1 wrote so far in this call
     float *blk_fe, *blk_fm, *blk_x0, *blk_xm;  // [nrows][nblk]
     TpCore* core;                              // [nrows][nseg+1]
+    TpCore* core_carry;                        // [nrows] chain state handed from one chunk's core kernel to the next
+    float* full0;                              // [nrows] pre_filter_.full_ at the start of the call
     int* rec;                                  // [TP_NREC][rec_stride]
     size_t rec_stride;
     int* tstart;                               // [nrows*nseg][8]
     int* need;                                 // [nrows*nseg]
     TpFinal* fin;                              // [nrows]
-    int* diag;                                 // [nrows][4]: segments not accepted in scan 0..3
+    int* diag;                                 // [nrows][4] segments not accepted in scan 0..3, then [nrows][4] core-chain block counts
     int scan_round;
-    hipEvent_t* kev;                           // TP_NKERN+1 events recorded between the launches, or null
 };
-constexpr int TP_NKERN = 13;
-extern const char* const kTpKernelNames[TP_NKERN];
+constexpr uint32_t TP_CHUNK_UNIT = 64000;  // lcm(TP_L = 512, WAVE_BATCH = 2000)
 
-hipError_t launch_tp(const TpArgs& a, hipStream_t s);
+// One chunk in three parts so the caller can put the serial part on its own stream:
+hipError_t launch_tp_front(const TpArgs& a, hipStream_t s);                        // (prologue on the first chunk) + k_tp_full
+hipError_t launch_tp_core(const TpArgs& a, hipStream_t s);                         // k_tp_core
+hipError_t launch_tp_back(const TpArgs& a, hipStream_t s, hipEvent_t* marks);      // k_tp_seg ... k_tp_finish; marks[0..4] optional
+constexpr int TP_BACK_MARKS = 4;  // marks: after seg, after scan#0, after fix#0, after finish
+
 
 hipError_t launch_channelize(const ChannelizeArgs& a, int log2n, int sfmt, int nstreams, hipStream_t s);
 hipError_t launch_demod(const DemodArgs& a, hipStream_t s);

@@ -59,7 +59,12 @@ struct mi_demod {
     size_t plane_stride = 0;
     hipStream_t own_stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t tpev[mi::TP_NKERN + 1] = {};
+    static constexpr int kMaxChunks = 64, kEvPerChunk = 10;
+    std::vector<hipEvent_t> chunk_ev;  // per chunk: stage1 begin/end, full end, core begin/end, back begin, seg/scan0/fix0/finish ends
+    hipStream_t aux_stream = nullptr;  // carries the serial core chain of the time-parallel path
+    int tp_chunks = 0;
+    mi::TpCore* d_core_carry = nullptr;
+    float* d_full0 = nullptr;
     bool ev_valid = false;
     // device memory
     float* d_window = nullptr;
@@ -177,20 +182,34 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     da.fm_quadri = h->plan.dev.fm_quadri;
     da.lanes_per_wave = lanes_per_wave_for(h->rows);
 
-    if (use_tp)
-        HIP_TRY(hipMemsetAsync(h->d_xmax, 0, static_cast<size_t>(h->rows) * sizeof(unsigned), s));
-    HIP_TRY(hipEventRecord(h->ev[0], s));
-    HIP_TRY(mi::launch_channelize(ca, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, s));
-    HIP_TRY(hipEventRecord(h->ev[1], s));
+    h->tp_chunks = 0;
     if (use_tp) {
+        // ---- time-parallel stage 2, pipelined over chunks of the call ----
+        // The exact core chain (k_tp_core) is serial per channel and latency bound on 8 waves; everything else is wide.
+        // Chunk i's core kernel runs on the handle's aux stream while stage 1 + k_tp_full of chunk i+1 and the
+        // segment / scan / fix passes of chunk i-1 run on the caller's stream.
+        const uint32_t n = da.nsteps;
+        const uint32_t units = n / mi::TP_CHUNK_UNIT;
+        int want = 2;  // measured best on MI355X: the wide passes take a fixed ~1.6 ms per launch, so few chunks
+        if (const char* e = std::getenv("MI_AIRBAND_TP_CHUNKS"))
+            want = std::max(1, std::atoi(e));
+        const uint32_t per = units == 0 ? 0 : (units + static_cast<uint32_t>(want) - 1) / static_cast<uint32_t>(want);
+        const int C = units == 0 ? 1 : static_cast<int>((units + per - 1) / per);
+        if (C > mi_demod::kMaxChunks)
+            return fail(MI_ERR_INVALID, "too many chunks");
+        while (static_cast<int>(h->chunk_ev.size()) < C * mi_demod::kEvPerChunk) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            h->chunk_ev.push_back(e);
+        }
         mi::TpArgs ta{};
         ta.rows = h->d_rows;
         ta.nrows = h->rows;
         ta.nch = h->nch;
-        ta.nsteps = da.nsteps;
+        ta.nsteps = n;
         ta.nbatches = da.nbatches;
-        ta.nblk = da.nsteps / 16;
-        ta.nseg = (da.nsteps + mi::TP_L - 1) / mi::TP_L;
+        ta.nblk = n / 16;
+        ta.nseg = (n + mi::TP_L - 1) / mi::TP_L;
         ta.mag = h->d_mag;
         ta.plane_stride = h->plane_stride;
         ta.wmain = d_wmain;
@@ -206,16 +225,81 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.blk_x0 = h->d_blk_x0;
         ta.blk_xm = h->d_blk_xm;
         ta.core = h->d_core;
+        ta.core_carry = h->d_core_carry;
+        ta.full0 = h->d_full0;
         ta.rec = h->d_rec;
         ta.rec_stride = static_cast<size_t>(h->rows) * h->tp_max_seg;
         ta.tstart = h->d_tstart;
         ta.need = h->d_need;
         ta.fin = h->d_fin;
         ta.diag = h->d_diag;
-        ta.kev = h->tpev;
         h->last_nseg = ta.nseg;
-        HIP_TRY(mi::launch_tp(ta, s));
+        auto chunk = [&](int i) {
+            mi::TpArgs c = ta;
+            c.step0 = units == 0 ? 0 : static_cast<uint32_t>(i) * per * mi::TP_CHUNK_UNIT;
+            c.step1 = (i == C - 1) ? n : (static_cast<uint32_t>(i) + 1) * per * mi::TP_CHUNK_UNIT;
+            c.seg0 = c.step0 / mi::TP_L;
+            c.seg1 = (c.step1 + mi::TP_L - 1) / mi::TP_L;
+            c.blk0 = c.step0 / 16;
+            c.blk1 = c.step1 / 16;
+            c.bat0 = c.step0 / mi::kWaveBatch;
+            c.bat1 = c.step1 / mi::kWaveBatch;
+            c.first_chunk = i == 0;
+            c.last_chunk = i == C - 1;
+            return c;
+        };
+        const bool first_call = h->first_call;
+        auto stage1 = [&](const mi::TpArgs& c) -> hipError_t {  // the windows whose magnitudes are the chunk's squelch samples
+            mi::ChannelizeArgs cc = ca;
+            const uint32_t f0 = first_call ? (c.first_chunk ? 0u : c.step0 + mi::kAgcExtra) : c.step0;
+            const uint32_t f1 = first_call ? c.step1 + mi::kAgcExtra : c.step1;
+            cc.iq = ca.iq + static_cast<size_t>(f0) * ca.hop_bytes;
+            cc.valid_bytes = ca.valid_bytes - static_cast<size_t>(f0) * ca.hop_bytes;
+            cc.nfft = f1 - f0;
+            cc.plane_off = ca.plane_off + f0;
+            return mi::launch_channelize(cc, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, s);
+        };
+        auto ev = [&](int i, int k) { return h->chunk_ev[static_cast<size_t>(i) * mi_demod::kEvPerChunk + k]; };
+        HIP_TRY(hipMemsetAsync(h->d_xmax, 0, static_cast<size_t>(h->rows) * sizeof(unsigned), s));
+        HIP_TRY(hipMemsetAsync(h->d_diag, 0, static_cast<size_t>(h->rows) * 8 * sizeof(int), s));
+        HIP_TRY(hipEventRecord(h->ev[0], s));
+        HIP_TRY(hipEventRecord(h->ev[1], s));
+        HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev[1], 0));  // the aux stream starts after everything queued so far
+        auto front = [&](int i) -> int {
+            const mi::TpArgs c = chunk(i);
+            HIP_TRY(hipEventRecord(ev(i, 0), s));
+            HIP_TRY(stage1(c));
+            HIP_TRY(hipEventRecord(ev(i, 1), s));
+            HIP_TRY(mi::launch_tp_front(c, s));
+            HIP_TRY(hipEventRecord(ev(i, 2), s));
+            return MI_OK;
+        };
+        for (int i = 0; i < C; ++i) {
+            if (i == 0) {
+                int rc = front(0);
+                if (rc != MI_OK)
+                    return rc;
+            }
+            if (i + 1 < C) {
+                int rc = front(i + 1);
+                if (rc != MI_OK)
+                    return rc;
+            }
+            const mi::TpArgs c = chunk(i);
+            HIP_TRY(hipStreamWaitEvent(h->aux_stream, ev(i, 2), 0));
+            HIP_TRY(hipEventRecord(ev(i, 3), h->aux_stream));
+            HIP_TRY(mi::launch_tp_core(c, h->aux_stream));
+            HIP_TRY(hipEventRecord(ev(i, 4), h->aux_stream));
+            HIP_TRY(hipStreamWaitEvent(s, ev(i, 4), 0));
+            HIP_TRY(hipEventRecord(ev(i, 5), s));
+            hipEvent_t marks[mi::TP_BACK_MARKS] = {ev(i, 6), ev(i, 7), ev(i, 8), ev(i, 9)};
+            HIP_TRY(mi::launch_tp_back(c, s, marks));
+        }
+        h->tp_chunks = C;
     } else {
+        HIP_TRY(hipEventRecord(h->ev[0], s));
+        HIP_TRY(mi::launch_channelize(ca, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, s));
+        HIP_TRY(hipEventRecord(h->ev[1], s));
         HIP_TRY(mi::launch_demod(da, s));
     }
     h->last_path = use_tp ? 1 : 0;
@@ -246,7 +330,7 @@ void mi_demod_destroy(mi_demod* h) {
     (void)hipSetDevice(h->gpu);
     void* ptrs[] = {h->d_window, h->d_tw,   h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_mag,   h->d_cplx, h->d_carry,
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc,
-                    h->d_rows,   h->d_xmax, h->d_blk_fe, h->d_blk_fm, h->d_blk_x0, h->d_blk_xm, h->d_core, h->d_rec, h->d_tstart, h->d_need, h->d_fin, h->d_diag};
+                    h->d_rows,   h->d_xmax, h->d_blk_fe, h->d_blk_fm, h->d_blk_x0, h->d_blk_xm, h->d_core, h->d_rec, h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0};
     for (void* p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -255,9 +339,11 @@ void mi_demod_destroy(mi_demod* h) {
     for (hipEvent_t e : h->ev)
         if (e)
             (void)hipEventDestroy(e);
-    for (hipEvent_t e : h->tpev)
+    for (hipEvent_t e : h->chunk_ev)
         if (e)
             (void)hipEventDestroy(e);
+    if (h->aux_stream)
+        (void)hipStreamDestroy(h->aux_stream);
     if (h->own_stream)
         (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -316,8 +402,7 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     TRY_OR_BAIL(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     for (auto& ev : h->ev)
         TRY_OR_BAIL(hipEventCreate(&ev));
-    for (auto& ev : h->tpev)
-        TRY_OR_BAIL(hipEventCreate(&ev));
+    TRY_OR_BAIL(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
     const size_t rows = static_cast<size_t>(h->rows);
     TRY_OR_BAIL(dalloc(&h->d_window, p.window.size()));
     TRY_OR_BAIL(dalloc(&h->d_tw, p.tw.size()));
@@ -368,6 +453,8 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
         TRY_OR_BAIL(dalloc(&h->d_need, rows * h->tp_max_seg));
         TRY_OR_BAIL(dalloc(&h->d_fin, rows));
         TRY_OR_BAIL(hipMemset(h->d_fin, 0, rows * sizeof(mi::TpFinal)));
+        TRY_OR_BAIL(dalloc(&h->d_core_carry, rows));
+        TRY_OR_BAIL(dalloc(&h->d_full0, rows));
         TRY_OR_BAIL(dalloc(&h->d_diag, rows * 8));
         TRY_OR_BAIL(hipMemset(h->d_diag, 0, rows * 8 * sizeof(int)));
     }
@@ -604,31 +691,41 @@ int mi_demod_read_planes(mi_demod* h, int stream, int ch, int first, int count, 
     return MI_OK;
 }
 
-int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms) {
+int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms_total, int* launches) {
     if (!h || !h->ev_valid || index < 0)
         return fail(MI_ERR_INVALID, "no call has been timed yet");
     HIP_TRY(hipSetDevice(h->gpu));
     HIP_TRY(hipEventSynchronize(h->ev[2]));
     float t = 0.f;
+    int n = 1;
     const char* nm = nullptr;
-    if (index == 0) {
-        nm = "k_channelize";
-        HIP_TRY(hipEventElapsedTime(&t, h->ev[0], h->ev[1]));
-    } else if (h->last_path == 0) {
-        if (index != 1)
+    if (h->last_path == 0) {
+        if (index > 1)
             return fail(MI_ERR_INVALID, "kernel index out of range");
-        nm = "k_demod";
-        HIP_TRY(hipEventElapsedTime(&t, h->ev[1], h->ev[2]));
+        nm = index == 0 ? "k_channelize" : "k_demod";
+        HIP_TRY(hipEventElapsedTime(&t, h->ev[index], h->ev[index + 1]));
     } else {
-        if (index > mi::TP_NKERN)
+        // per chunk events: 0 stage1 begin, 1 stage1 end, 2 k_tp_full end, 3 core begin, 4 core end, 5 back begin,
+        // 6 seg end, 7 scan#0 end, 8 fix#0 end, 9 finish end
+        static const char* const names[] = {"k_channelize", "k_tp_full", "k_tp_core", "k_tp_seg", "k_tp_scan#0", "k_tp_fix#0", "k_tp_rest"};
+        static const int from[] = {0, 1, 3, 5, 6, 7, 8}, to[] = {1, 2, 4, 6, 7, 8, 9};
+        if (index > 6)
             return fail(MI_ERR_INVALID, "kernel index out of range");
-        nm = mi::kTpKernelNames[index - 1];
-        HIP_TRY(hipEventElapsedTime(&t, h->tpev[index - 1], h->tpev[index]));
+        nm = names[index];
+        n = h->tp_chunks;
+        for (int i = 0; i < h->tp_chunks; ++i) {
+            float d = 0.f;
+            HIP_TRY(hipEventElapsedTime(&d, h->chunk_ev[static_cast<size_t>(i) * mi_demod::kEvPerChunk + from[index]],
+                                        h->chunk_ev[static_cast<size_t>(i) * mi_demod::kEvPerChunk + to[index]]));
+            t += d;
+        }
     }
     if (name)
         *name = nm;
-    if (ms)
-        *ms = t;
+    if (ms_total)
+        *ms_total = t;
+    if (launches)
+        *launches = n;
     return MI_OK;
 }
 
@@ -638,8 +735,17 @@ int mi_demod_last_kernel_ms(mi_demod* h, float* channelize_ms, float* demod_ms) 
     HIP_TRY(hipSetDevice(h->gpu));
     HIP_TRY(hipEventSynchronize(h->ev[2]));
     float a = 0.f, b = 0.f;
-    HIP_TRY(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+    if (h->last_path == 0) {
+        HIP_TRY(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+    } else {  // pipelined: stage 1 summed over the chunks, stage 2 = the rest of the call's wall time on the stream
+        float total = 0.f;
+        HIP_TRY(hipEventElapsedTime(&total, h->ev[0], h->ev[2]));
+        int rc = mi_demod_kernel_time(h, 0, nullptr, &a, nullptr);
+        if (rc != MI_OK)
+            return rc;
+        b = total - a;
+    }
     if (channelize_ms)
         *channelize_ms = a;
     if (demod_ms)

@@ -75,22 +75,23 @@ __device__ __forceinline__ float level_of(const ChanParams& p, const float nf, c
 // P1: pre_filter_.full_ by sandwich, and the per-block aggregates
 // =====================================================================================================
 __global__ __launch_bounds__(64) void k_tp_full(const TpArgs a) {
-    const int lanes_per_row = (a.nsteps + TP_L1 - 1) / TP_L1;
+    const int lanes_per_row = (a.step1 - a.step0 + TP_L1 - 1) / TP_L1;  // this chunk's lanes
     const int gid = blockIdx.x * 64 + threadIdx.x;
     if (gid >= a.nrows * lanes_per_row)
         return;
     const int r = gid / lanes_per_row, q = gid - r * lanes_per_row;
     const int row = a.rows[r];
     const float* __restrict__ x = a.mag + static_cast<size_t>(row) * a.plane_stride + kAgcExtra;
-    const uint32_t t0 = static_cast<uint32_t>(q) * TP_L1;
-    const uint32_t t1 = min(t0 + TP_L1, a.nsteps);
+    const uint32_t t0 = a.step0 + static_cast<uint32_t>(q) * TP_L1;
+    const uint32_t t1 = min(t0 + TP_L1, a.step1);
     const uint32_t tw = t0 > TP_W1 ? t0 - TP_W1 : 0;
     float lo, hi;
     if (tw == 0) {
         lo = hi = a.st[row].pre_full;  // the true value: exact from the first step
     } else {
         lo = 0.0f;
-        const float mx = fmaxf(__uint_as_float(a.xmax[row]), a.st[row].pre_full);
+        // any earlier value of full_ is bounded by its value at the start of the call and the largest sample so far
+        const float mx = fmaxf(__uint_as_float(a.xmax[row]), a.full0[r]);
         hi = mx * 1.0001f + 1e-30f;
     }
     for (uint32_t i = tw; i < t0; i += 4) {  // warm-up (tw and t0 are multiples of 16)
@@ -153,7 +154,7 @@ __device__ __forceinline__ CoreGroup core_load(const TpArgs& a, const float* __r
     g.fe = 0.f, g.fm = -1.f, g.x0 = 0.f, g.xm = 0.f;
     g.s0 = g.s1 = g.s2 = g.s3 = make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t mine = g0 + lane;
-    if (mine < a.nblk) {
+    if (mine < a.blk1) {
         g.fe = a.blk_fe[bbase + mine];
         g.fm = a.blk_fm[bbase + mine];
         g.x0 = a.blk_x0[bbase + mine];
@@ -179,15 +180,15 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
     TpCore* __restrict__ core = a.core + static_cast<size_t>(r) * (a.nseg + 1);
 
     // every lane carries the same chain values (wave-uniform); lanes differ in the block they prefetched
-    float nf = a.st[row].noise_floor, cap = a.st[row].moving_avg_cap, c = a.st[row].pre_capped, full = a.st[row].pre_full;
-    const uint32_t nblk = a.nblk;
+    // the chain state comes from the previous chunk's core kernel (k_tp_prologue seeds it from the carried ChanState)
+    float nf = a.core_carry[r].nf, cap = a.core_carry[r].cap, c = a.core_carry[r].c, full = a.core_carry[r].full;
+    const uint32_t nblk = a.blk1;
     constexpr uint32_t bps = TP_L / 16;  // blocks per segment
 
     int n_run = 0, n_single = 0, n_step = 0, n_fail = 0;  // diagnostics: blocks per path, failed hypotheses
-    long long t_loop = 0, t_step = 0, t_all = clock64();
-    CoreGroup nxt = core_load(a, x, bbase, 0, lane);
-    CoreGroup nxt2 = core_load(a, x, bbase, 64, lane);
-    for (uint32_t g0 = 0; g0 < nblk; g0 += 64) {
+    CoreGroup nxt = core_load(a, x, bbase, a.blk0, lane);
+    CoreGroup nxt2 = core_load(a, x, bbase, a.blk0 + 64, lane);
+    for (uint32_t g0 = a.blk0; g0 < nblk; g0 += 64) {
         const CoreGroup cur = nxt;
         nxt = nxt2;
         if (g0 + 128 < nblk)
@@ -207,7 +208,6 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                 // No scalar loop-carried value, no lane writes: ~8 VALU per block on the serial chain.
                 const bool upd = lane >= kk;
                 float vnf = nf;
-                const long long tl0 = clock64();
                 if (merged) {
                     const float cen = (lane == kk) ? c : fe_prev;  // capped_ (== full_) entering the lane's block
                     if (kk == 0) {  // the common case, a whole group: every lane updates
@@ -237,7 +237,6 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                     }
                 }
                 const float nf_prev = wave_shr1(vnf, nf);  // lanes <= kk read the current state
-                t_loop += clock64() - tl0;
                 const float cap_prev = (lane == kk) ? cap : cap_of(p, nf_prev);
                 const float capj = cap_of(p, vnf);
                 const float full_entry = (lane == kk) ? full : fe_prev;
@@ -286,7 +285,6 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                 full = fe;
             } else {  // STEP: the 16 samples one by one
                 ++n_step;
-                const long long ts0 = clock64();
                 const float xs[16] = {rl(cur.s0.x, kk), rl(cur.s0.y, kk), rl(cur.s0.z, kk), rl(cur.s0.w, kk), rl(cur.s1.x, kk), rl(cur.s1.y, kk),
                                       rl(cur.s1.z, kk), rl(cur.s1.w, kk), rl(cur.s2.x, kk), rl(cur.s2.y, kk), rl(cur.s2.z, kk), rl(cur.s2.w, kk),
                                       rl(cur.s3.x, kk), rl(cur.s3.y, kk), rl(cur.s3.z, kk), rl(cur.s3.w, kk)};
@@ -326,7 +324,6 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                         c = capped_step(c, xs[j], cap);
                     }
                 }
-                t_step += clock64() - ts0;
             }
             ++kk;
         }
@@ -334,12 +331,13 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
     if (lane == 0) {
         TpCore t;
         t.nf = nf, t.cap = cap, t.c = c, t.full = full;
-        core[a.nseg] = t;
+        core[(a.blk1 + bps - 1) / bps] = t;  // = the next chunk's first boundary, or the end of the call
+        a.core_carry[r] = t;
         if (a.diag) {
-            a.diag[a.nrows * 4 + r * 4 + 0] = n_run + 0 * n_single;
-            a.diag[a.nrows * 4 + r * 4 + 1] = static_cast<int>(t_loop >> 4);
-            a.diag[a.nrows * 4 + r * 4 + 2] = static_cast<int>(t_step >> 4);
-            a.diag[a.nrows * 4 + r * 4 + 3] = static_cast<int>((clock64() - t_all) >> 4) + 0 * (n_step + n_fail);
+            a.diag[a.nrows * 4 + r * 4 + 0] += n_run;
+            a.diag[a.nrows * 4 + r * 4 + 1] += n_single;
+            a.diag[a.nrows * 4 + r * 4 + 2] += n_step;
+            a.diag[a.nrows * 4 + r * 4 + 3] += n_fail;
         }
     }
 }
@@ -574,8 +572,20 @@ __device__ __forceinline__ void tp_chunk(TpLane& s, const ChanParams& p, const T
                 for (int k = 0; k < 4; ++k) {
                     if (xv[k] > t_level)
                         s.agc = s.agc * 0.995f + xv[k] * 0.005f;
-                    float wout = (av[k] - s.agc) / (s.agc * 1.5f);
-                    if (fabsf(wout) > 0.8f) {
+                    // The AGC clip feedback (rtl_airband.cpp:580-584) puts the correctly rounded division on the serial
+                    // chain.  Its outcome |waveout| > 0.8 is decided from a reciprocal estimate (relative error < 3e-7)
+                    // unless the quotient is within 1 % of the threshold; the exact quotient is still the audio sample.
+                    const float num = av[k] - s.agc, den = s.agc * 1.5f;
+                    const float qa = fabsf(num) * __builtin_amdgcn_rcpf(den);
+                    float wout = num / den;
+                    bool clip;
+                    if (qa < 0.79f)
+                        clip = false;
+                    else if (qa > 0.81f)
+                        clip = true;
+                    else
+                        clip = fabsf(wout) > 0.8f;  // also taken when the estimate is not a number
+                    if (clip) {
                         wout *= 0.85f;
                         s.agc *= 1.15f;
                     }
@@ -675,10 +685,11 @@ __device__ __forceinline__ void load_core(TpLane& s, const ChanParams& p, const 
 
 __global__ __launch_bounds__(64) void k_tp_seg(const TpArgs a) {
     const int gid = blockIdx.x * 64 + threadIdx.x;
-    if (gid >= a.nrows * static_cast<int>(a.nseg))
+    const int nsc = static_cast<int>(a.seg1 - a.seg0);  // segments of this chunk
+    if (gid >= a.nrows * nsc)
         return;
-    const int r = gid / a.nseg;
-    const uint32_t k = gid - r * a.nseg;
+    const int r = gid / nsc;
+    const uint32_t k = a.seg0 + static_cast<uint32_t>(gid - r * nsc);
     const int row = a.rows[r];
     const ChanParams p = a.cp[row % a.nch];
     const float* __restrict__ magrow = a.mag + static_cast<size_t>(row) * a.plane_stride;
@@ -739,12 +750,12 @@ __global__ __launch_bounds__(64) void k_tp_scan(const TpArgs a) {
     TpFsm carryE = canon(init);
     float carryA = init.agc;
     bool all_ok = true;  // every segment so far accepted: carryE / carryA are the TRUE state
-    uint32_t first_bad = a.nseg;
+    uint32_t first_bad = a.seg1;
     int sum_open = 0, sum_flappy = 0, nbad = 0;
 
-    for (uint32_t g0 = 0; g0 < a.nseg; g0 += 64) {
+    for (uint32_t g0 = a.seg0; g0 < a.seg1; g0 += 64) {
         const uint32_t k = g0 + lane;
-        const bool have = k < a.nseg;
+        const bool have = k < a.seg1;
         TpFsm S{}, E{};
         float s_agc = 0.f, e_agc = 0.f;
         int uses = 0, d_open = 0, d_flappy = 0;
@@ -816,7 +827,7 @@ __global__ __launch_bounds__(64) void k_tp_scan(const TpArgs a) {
         f.d_flappy = sum_flappy;
         a.fin[r] = f;
         if (a.diag)
-            a.diag[r * 4 + (a.scan_round & 3)] = nbad;
+            a.diag[r * 4 + (a.scan_round & 3)] += nbad;
     }
 }
 
@@ -836,7 +847,7 @@ __device__ __forceinline__ void rerun_chain(const TpArgs& a, const int r, const 
     seg_reset(s);
     lane_from_tstart(s, a.tstart + (base + k) * 8);
     load_core(s, p, a.core[static_cast<size_t>(r) * (a.nseg + 1) + k]);
-    for (uint32_t done = 0; k < a.nseg; ++k, ++done) {
+    for (uint32_t done = 0; k < a.seg1; ++k, ++done) {  // never beyond this chunk
         if (done > 0 && !to_the_end) {
             if (done >= max_chain)
                 return;
@@ -860,10 +871,11 @@ __device__ __forceinline__ void rerun_chain(const TpArgs& a, const int r, const 
 
 __global__ __launch_bounds__(64) void k_tp_fix(const TpArgs a) {
     const int gid = blockIdx.x * 64 + threadIdx.x;
-    if (gid >= a.nrows * static_cast<int>(a.nseg))
+    const int nsc = static_cast<int>(a.seg1 - a.seg0);
+    if (gid >= a.nrows * nsc)
         return;
-    const int r = gid / a.nseg;
-    const uint32_t k = gid - r * a.nseg;
+    const int r = gid / nsc;
+    const uint32_t k = a.seg0 + static_cast<uint32_t>(gid - r * nsc);
     if (!a.need[static_cast<size_t>(r) * a.nseg + k])
         return;
     const int row = a.rows[r];
@@ -890,10 +902,11 @@ __global__ __launch_bounds__(64) void k_tp_fallback(const TpArgs a) {
 // =====================================================================================================
 __global__ __launch_bounds__(64) void k_tp_fades(const TpArgs a) {
     const int gid = blockIdx.x * 64 + threadIdx.x;
-    if (gid >= a.nrows * static_cast<int>(a.nseg))
+    const int nsc = static_cast<int>(a.seg1 - a.seg0);
+    if (gid >= a.nrows * nsc)
         return;
-    const int r = gid / a.nseg;
-    const uint32_t k = gid - r * a.nseg;
+    const int r = gid / nsc;
+    const uint32_t k = a.seg0 + static_cast<uint32_t>(gid - r * nsc);
     const int row = a.rows[r];
     const size_t idx = static_cast<size_t>(r) * a.nseg + k;
     const int nev = a.rec[18 * a.rec_stride + idx];
@@ -921,7 +934,7 @@ __global__ __launch_bounds__(64) void k_tp_finish(const TpArgs a) {
     const size_t base = static_cast<size_t>(r) * a.nseg;
     // axcindicate per WAVE_BATCH from the segments' open masks
     int nopen = 0;
-    for (uint32_t b = lane; b < a.nbatches; b += 64) {
+    for (uint32_t b = a.bat0 + lane; b < a.bat1; b += 64) {
         const uint32_t kmin = (b * kWaveBatch) / TP_L, kmax = min((b * kWaveBatch + kWaveBatch - 1) / TP_L, a.nseg - 1);
         bool open = false;
         for (uint32_t k = kmin; k <= kmax; ++k) {
@@ -936,12 +949,13 @@ __global__ __launch_bounds__(64) void k_tp_finish(const TpArgs a) {
         nopen += __shfl_xor(nopen, off);
     // the magnitude plane's last AGC_EXTRA samples move to the front (rtl_airband.cpp:643)
     float* __restrict__ magrow = a.mag + static_cast<size_t>(row) * a.plane_stride;
-    for (int v = lane; v < kAgcExtra; v += 64)
-        magrow[v] = magrow[a.nsteps + v];
+    if (a.last_chunk)
+        for (int v = lane; v < kAgcExtra; v += 64)
+            magrow[v] = magrow[a.nsteps + v];
     if (lane != 0)
         return;
     const TpFinal f = a.fin[r];
-    const TpCore t = a.core[static_cast<size_t>(r) * (a.nseg + 1) + a.nseg];
+    const TpCore t = a.core[static_cast<size_t>(r) * (a.nseg + 1) + (a.blk1 + TP_L / 16 - 1) / (TP_L / 16)];  // end of this chunk
     const ChanParams p = a.cp[row % a.nch];
     ChanState cs = a.st[row];
     cs.noise_floor = t.nf;
@@ -955,9 +969,9 @@ __global__ __launch_bounds__(64) void k_tp_finish(const TpArgs a) {
     cs.low_signal_count = f.low;
     cs.recent_open_count = static_cast<uint32_t>(f.recent);
     cs.closed_sample_count = static_cast<uint32_t>(f.closed);
-    cs.sample_count += a.nsteps;
-    cs.buffer_head = static_cast<int32_t>((static_cast<uint32_t>(cs.buffer_head) + a.nsteps) % kSquelchRing);
-    cs.buffer_tail = static_cast<int32_t>((static_cast<uint32_t>(cs.buffer_tail) + a.nsteps) % kSquelchRing);
+    cs.sample_count += a.step1 - a.step0;
+    cs.buffer_head = static_cast<int32_t>((static_cast<uint32_t>(cs.buffer_head) + (a.step1 - a.step0)) % kSquelchRing);
+    cs.buffer_tail = static_cast<int32_t>((static_cast<uint32_t>(cs.buffer_tail) + (a.step1 - a.step0)) % kSquelchRing);
     cs.open_count += static_cast<uint64_t>(f.d_open);
     cs.flappy_count += static_cast<uint64_t>(f.d_flappy);
     cs.agcavgfast = f.agc;
@@ -982,6 +996,13 @@ __global__ __launch_bounds__(64) void k_tp_finish(const TpArgs a) {
 // head of the emitted audio = lookahead of the previous call (output.cpp:948); runs before any segment writes
 __global__ void k_tp_prologue(const TpArgs a) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < a.nrows) {  // seed of the core chain
+        const ChanState& cs = a.st[a.rows[gid]];
+        TpCore t;
+        t.nf = cs.noise_floor, t.cap = cs.moving_avg_cap, t.c = cs.pre_capped, t.full = cs.pre_full;
+        a.core_carry[gid] = t;
+        a.full0[gid] = cs.pre_full;
+    }
     if (gid >= a.nrows * kAgcExtra)
         return;
     const int r = gid / kAgcExtra, v = gid - r * kAgcExtra;
@@ -999,52 +1020,56 @@ __global__ void k_tp_prologue(const TpArgs a) {
             return e__;                                           \
     } while (0)
 
-const char* const kTpKernelNames[TP_NKERN] = {"k_tp_prologue", "k_tp_full", "k_tp_core",  "k_tp_seg",      "k_tp_scan#0", "k_tp_fix#0", "k_tp_scan#1",
-                                              "k_tp_fix#1",    "k_tp_scan#2", "k_tp_fallback", "k_tp_scan#3", "k_tp_fades", "k_tp_finish"};
+hipError_t launch_tp_front(const TpArgs& a, hipStream_t s) {
+    if (a.nrows == 0 || a.step1 <= a.step0)
+        return hipSuccess;
+    if (a.first_chunk)
+        TP_LAUNCH(k_tp_prologue, (a.nrows * kAgcExtra + 255) / 256, 256);
+    const int lanes1 = a.nrows * static_cast<int>((a.step1 - a.step0 + TP_L1 - 1) / TP_L1);
+    TP_LAUNCH(k_tp_full, (lanes1 + 63) / 64, 64);
+    return hipSuccess;
+}
 
-#define TP_MARK(i)                                        \
-    do {                                                  \
-        if (a.kev) {                                      \
-            hipError_t e__ = hipEventRecord(a.kev[i], s); \
-            if (e__ != hipSuccess)                        \
-                return e__;                               \
-        }                                                 \
+hipError_t launch_tp_core(const TpArgs& a, hipStream_t s) {
+    if (a.nrows == 0 || a.step1 <= a.step0)
+        return hipSuccess;
+    TP_LAUNCH(k_tp_core, a.nrows, 64);
+    return hipSuccess;
+}
+
+#define TP_MARK(i)                                         \
+    do {                                                   \
+        if (marks) {                                       \
+            hipError_t e__ = hipEventRecord(marks[i], s);  \
+            if (e__ != hipSuccess)                         \
+                return e__;                                \
+        }                                                  \
     } while (0)
 
-hipError_t launch_tp(const TpArgs& a_in, hipStream_t s) {
+hipError_t launch_tp_back(const TpArgs& a_in, hipStream_t s, hipEvent_t* marks) {
     TpArgs a = a_in;
-    if (a.nrows == 0 || a.nsteps == 0)
+    if (a.nrows == 0 || a.step1 <= a.step0)
         return hipSuccess;
-    const int lanes1 = a.nrows * static_cast<int>((a.nsteps + TP_L1 - 1) / TP_L1);
-    const int lanes = a.nrows * static_cast<int>(a.nseg);
-    TP_MARK(0);
-    TP_LAUNCH(k_tp_prologue, (a.nrows * kAgcExtra + 255) / 256, 256);
-    TP_MARK(1);
-    TP_LAUNCH(k_tp_full, (lanes1 + 63) / 64, 64);
-    TP_MARK(2);
-    TP_LAUNCH(k_tp_core, a.nrows, 64);
-    TP_MARK(3);
+    const int lanes = a.nrows * static_cast<int>(a.seg1 - a.seg0);
     TP_LAUNCH(k_tp_seg, (lanes + 63) / 64, 64);
+    TP_MARK(0);
     for (int round = 0; round < 2; ++round) {
         a.scan_round = round;
-        TP_MARK(4 + 2 * round);
         TP_LAUNCH(k_tp_scan, a.nrows, 64);
-        TP_MARK(5 + 2 * round);
+        if (round == 0)
+            TP_MARK(1);
         TP_LAUNCH(k_tp_fix, (lanes + 63) / 64, 64);
+        if (round == 0)
+            TP_MARK(2);
     }
     a.scan_round = 2;
-    TP_MARK(8);
     TP_LAUNCH(k_tp_scan, a.nrows, 64);
-    TP_MARK(9);
     TP_LAUNCH(k_tp_fallback, (a.nrows + 63) / 64, 64);
     a.scan_round = 3;
-    TP_MARK(10);
     TP_LAUNCH(k_tp_scan, a.nrows, 64);
-    TP_MARK(11);
     TP_LAUNCH(k_tp_fades, (lanes + 63) / 64, 64);
-    TP_MARK(12);
     TP_LAUNCH(k_tp_finish, a.nrows, 64);
-    TP_MARK(13);
+    TP_MARK(3);
     return hipSuccess;
 }
 

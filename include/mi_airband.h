@@ -160,11 +160,13 @@ int mi_demod_read_planes(mi_demod* h, int stream, int ch, int first, int count, 
  * recorded around each launch (ms; synchronises). */
 int mi_demod_last_kernel_ms(mi_demod* h, float* channelize_ms, float* demod_ms);
 
-/* Per-kernel timing of the last mi_demod_process_device() call, from HIP events recorded on its launch
- * stream between the launches.  index 0 is the channelize kernel; then "k_demod" (serial path) or the
- * kernels of the time-parallel path in launch order.  Returns MI_ERR_INVALID past the last index, so a
- * caller iterates from 0 until it fails.  *name points to a static string.  Synchronises. */
-int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms);
+/* Per-kernel timing of the last call, from HIP events recorded on the launch streams around the launches.
+ * index 0 is the channelize kernel; then "k_demod" (serial path) or the kernels of the time-parallel path
+ * ("k_tp_full", "k_tp_core", "k_tp_seg", "k_tp_scan#0", "k_tp_fix#0", "k_tp_rest" = the remaining small launches).
+ * The time-parallel path runs a long call in chunks, so a kernel is launched *launches times; *ms_total is the
+ * sum over those launches (kernels of different chunks overlap on two streams, so the sums exceed the wall time).
+ * Returns MI_ERR_INVALID past the last index: iterate from 0 until it fails.  *name is a static string. */
+int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms_total, int* launches);
 
 /* ---- host-only views of the derived plan (no GPU needed; used by the CPU test-suite) ---- */
 typedef struct mi_plan mi_plan;
