@@ -144,6 +144,60 @@ __device__ __forceinline__ float wave_shr1(const float v, const float first) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
 
+// ---- the noise-floor chain of a run of blocks, systolic over the lanes of one wave ----
+// Lane l returns f_l(f_{l-1}(... f_first(nf))) where f_j(v) = v*0.97 + min(operand_j, v)*0.03 + 1e-6 (noise_floor_step) and
+// `first` is the lowest active lane.  Call with EXEC = lanes >= first, the same `nf` on every lane and `passes` >= the
+// number of lanes to settle.  The shifted source of lane `first` is invalid (lane 0: out of range; otherwise: disabled,
+// and it holds nf anyway), so its DPP writes are dropped (bound_ctrl:0) and it keeps the pre-set values for input nf.
+// The two s_nop cover the VALU-write -> DPP-read hazard (2 wait states), which the compiler cannot see inside asm.
+#define NF_DPP " wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+__device__ __forceinline__ float nf_chain_min(const float nf, const float operand, const int passes) {
+    const float k97 = 0.97f, k03 = static_cast<float>(1.0 - static_cast<double>(0.97f));
+    float v = nf, m, a = nf * k97, b;
+    asm volatile("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(operand), "v"(nf));
+    for (int t = 0; t < passes; ++t)
+        asm volatile("s_nop 1\n"
+                     "v_min_f32_dpp %1, %0, %4" NF_DPP
+                     "v_mul_f32_dpp %2, %0, %5" NF_DPP
+                     "v_mul_f32 %3, %6, %1\n"
+                     "v_add_f32 %0, %2, %3\n"
+                     "v_add_f32 %0, 0x358637bd, %0"
+                     : "+v"(v), "+v"(m), "+v"(a), "=&v"(b)
+                     : "v"(operand), "v"(k97), "v"(k03));
+    return v;
+}
+// operand_j = the chain value itself (capped_ == cap >= noise floor): min() is the identity
+__device__ __forceinline__ float nf_chain_self(const float nf, const int passes) {
+    const float k97 = 0.97f, k03 = static_cast<float>(1.0 - static_cast<double>(0.97f));
+    float v = nf, a = nf * k97, b = nf * k03;
+    for (int t = 0; t < passes; ++t)
+        asm volatile("s_nop 1\n"
+                     "v_mul_f32_dpp %1, %0, %3" NF_DPP
+                     "v_mul_f32_dpp %2, %0, %4" NF_DPP
+                     "v_add_f32 %0, %1, %2\n"
+                     "v_add_f32 %0, 0x358637bd, %0"
+                     : "+v"(v), "+v"(a), "+v"(b)
+                     : "v"(k97), "v"(k03));
+    return v;
+}
+// operand_j = scale * chain value with scale < 1 (an SNR threshold below 0 dB)
+__device__ __forceinline__ float nf_chain_scaled(const float nf, const float scale, const int passes) {
+    const float k97 = 0.97f, k03 = static_cast<float>(1.0 - static_cast<double>(0.97f));
+    float v = nf, a = nf * k97, m = nf * scale, b;
+    asm volatile("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(nf));
+    for (int t = 0; t < passes; ++t)
+        asm volatile("s_nop 1\n"
+                     "v_mul_f32_dpp %1, %0, %4" NF_DPP
+                     "v_min_f32_dpp %1, %0, %1" NF_DPP
+                     "v_mul_f32_dpp %2, %0, %5" NF_DPP
+                     "v_mul_f32 %3, %6, %1\n"
+                     "v_add_f32 %0, %2, %3\n"
+                     "v_add_f32 %0, 0x358637bd, %0"
+                     : "+v"(v), "+v"(m), "+v"(a), "=&v"(b)
+                     : "v"(scale), "v"(k97), "v"(k03));
+    return v;
+}
+
 struct CoreGroup {  // what lane l holds for block g0 + l
     float fe, fm, x0, xm;
     float4 s0, s1, s2, s3;  // the block's 16 raw samples (only read when the block has to be stepped)
@@ -202,38 +256,22 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                 // Hypothesis: the regime of the current block persists.  The noise-floor chain is walked serially
                 // (the only true dependence), every block's precondition is then checked by its own lane.
                 const bool merged = (c == full);
-                // Systolic evaluation: lane j holds "noise floor after block j"; every pass shifts the vector one lane up
-                // (v_mov_dpp wave_shr:1), applies the update with the lane's own operand and keeps lanes below kk at
-                // the current state.  After pass t lanes kk .. kk+t-1 are final; nb-kk passes settle the whole group.
-                // No scalar loop-carried value, no lane writes: ~8 VALU per block on the serial chain.
-                const bool upd = lane >= kk;
+                // Systolic evaluation: lane j holds "noise floor after block j".  A lone wave issues one VALU instruction
+                // every ~2.6 ns whether or not it depends on the previous one (tools/valu_latency.hip), so the chain is
+                // priced in instructions per block, not in depth: each pass is 5 (4) VALU with the one-lane shift folded
+                // into the consuming operations as a DPP modifier (nf_chain_*), no lane reads or writes.
+                // After pass t lanes kk .. kk+t-1 are final; nb-kk passes settle the whole group.
                 float vnf = nf;
-                if (merged) {
-                    const float cen = (lane == kk) ? c : fe_prev;  // capped_ (== full_) entering the lane's block
-                    if (kk == 0) {  // the common case, a whole group: every lane updates
-#pragma unroll 4
-                        for (int it = 0; it < nb; ++it)
-                            vnf = noise_floor_step(wave_shr1(vnf, nf), cen);
+                if (lane >= kk) {  // lanes below kk keep the current state; lane kk never sees a valid shifted source
+                    if (merged) {
+                        const float cen = (lane == kk) ? c : fe_prev;  // capped_ (== full_) entering the lane's block
+                        vnf = nf_chain_min(nf, cen, nb - kk);
+                    } else if (p.using_manual_level) {
+                        vnf = nf_chain_min(nf, p.manual_cap, nb - kk);  // capped_ == cap entering the block
+                    } else if (p.cap_factor >= 1.0f) {
+                        vnf = nf_chain_self(nf, nb - kk);  // min(cap_factor * nf, nf) == nf
                     } else {
-                        for (int it = kk; it < nb; ++it) {
-                            const float prev = wave_shr1(vnf, nf);
-                            const float nv = noise_floor_step(prev, cen);
-                            vnf = upd ? nv : vnf;
-                        }
-                    }
-                } else {
-                    if (kk == 0) {
-#pragma unroll 4
-                        for (int it = 0; it < nb; ++it) {
-                            const float prev = wave_shr1(vnf, nf);
-                            vnf = noise_floor_step(prev, cap_of(p, prev));  // capped_ == cap entering the block
-                        }
-                    } else {
-                        for (int it = kk; it < nb; ++it) {
-                            const float prev = wave_shr1(vnf, nf);
-                            const float nv = noise_floor_step(prev, cap_of(p, prev));
-                            vnf = upd ? nv : vnf;
-                        }
+                        vnf = nf_chain_scaled(nf, p.cap_factor, nb - kk);
                     }
                 }
                 const float nf_prev = wave_shr1(vnf, nf);  // lanes <= kk read the current state
