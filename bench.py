@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="length of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--noise-only", action="store_true", help="diagnostic: no carriers in the synthetic capture (squelch never opens)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of audio to rank 0 (N>1)")
+    ap.add_argument("--diag", action="store_true", help="print the time-parallel path's per-channel counters to stderr")
     args = ap.parse_args()
 
     import torch
@@ -146,6 +147,9 @@ def main():
     total_samples = samples_per_step_per_gpu * args.steps * world
     value = total_samples / dt / 1e6  # MS/s, whole job
 
+    if args.diag and rank == 0 and h.last_path()[0] == 1:
+        for c in range(nch):
+            print(f"diag ch{c}: {h.tp_debug(c)[1].tolist()}", file=sys.stderr)
     if rank == 0:
         # algorithmic HBM bytes per complex input sample, per kernel (DESIGN.md "Kernels"); hop = 160 samples
         hopn = SAMPLE_RATE // 16000

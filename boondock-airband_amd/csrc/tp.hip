@@ -250,6 +250,8 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
         const int nb = static_cast<int>(min(64u, nblk - g0));
         const float fe_prev = __shfl_up(cur.fe, 1);  // full_ at the start of lane's block, valid for lane > kk
         const bool boundary = ((g0 + lane) % bps) == 0;
+        bool ys_ready = false;
+        float yv[16];
         int kk = 0;
         while (kk < nb) {
             if (c == full || c == cap) {
@@ -323,39 +325,51 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                 full = fe;
             } else {  // STEP: the 16 samples one by one
                 ++n_step;
-                const float xs[16] = {rl(cur.s0.x, kk), rl(cur.s0.y, kk), rl(cur.s0.z, kk), rl(cur.s0.w, kk), rl(cur.s1.x, kk), rl(cur.s1.y, kk),
-                                      rl(cur.s1.z, kk), rl(cur.s1.w, kk), rl(cur.s2.x, kk), rl(cur.s2.y, kk), rl(cur.s2.z, kk), rl(cur.s2.w, kk),
-                                      rl(cur.s3.x, kk), rl(cur.s3.y, kk), rl(cur.s3.z, kk), rl(cur.s3.w, kk)};
                 if (valid) {  // full_ at the block end is already known exactly: only the capped_ chain is serial
-                    // capped_step() with everything that does not depend on c hoisted off the chain: y = x*b, and the
-                    // shortcut "c >= cap && x >= cap" as "c >= t" with t = cap where x >= cap, +inf elsewhere.
-                    const float nfac = static_cast<float>(1.0 - static_cast<double>(0.99f));
-                    float ys[16], ts[16];
+                    // Everything that does not depend on c is done once per group, by all 64 lanes for their own blocks
+                    // (y = x*b); a stepped block then costs 16 lane reads and the chain.
+                    if (!ys_ready) {
+                        const float nfac = static_cast<float>(1.0 - static_cast<double>(0.99f));
+                        const float xv[16] = {cur.s0.x, cur.s0.y, cur.s0.z, cur.s0.w, cur.s1.x, cur.s1.y, cur.s1.z, cur.s1.w,
+                                              cur.s2.x, cur.s2.y, cur.s2.z, cur.s2.w, cur.s3.x, cur.s3.y, cur.s3.z, cur.s3.w};
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        ys[j] = xs[j] * nfac;
-                        ts[j] = (xs[j] >= cap) ? cap : __int_as_float(0x7f800000);
+                        for (int j = 0; j < 16; ++j)
+                            yv[j] = xv[j] * nfac;
+                        ys_ready = true;
                     }
+                    float ys[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        ys[j] = rl(yv[j], kk);
                     // Trial: the cap does not bind anywhere in the block (the decay after a burst).  Then capped_ is the
-                    // bare EMA, two dependent operations per sample; accepted iff every value stayed below the cap.
+                    // bare EMA, two operations per sample; accepted iff every value stayed below the cap.
                     float cs = c, emax = c;
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        cs = cs * 0.99f + ys[j];
-                        emax = fmaxf(emax, cs);
+                    for (int j = 0; j < 16; j += 2) {
+                        const float c1 = cs * 0.99f + ys[j];
+                        cs = c1 * 0.99f + ys[j + 1];
+                        emax = fmaxf(fmaxf(emax, c1), cs);
                     }
                     if (emax < cap) {
                         c = cs;
                     } else {
+                        // capped_step() with the shortcut "c >= cap && x >= cap" as "c >= t", t = cap where x >= cap, +inf elsewhere
+                        const float xs[16] = {rl(cur.s0.x, kk), rl(cur.s0.y, kk), rl(cur.s0.z, kk), rl(cur.s0.w, kk), rl(cur.s1.x, kk), rl(cur.s1.y, kk),
+                                              rl(cur.s1.z, kk), rl(cur.s1.w, kk), rl(cur.s2.x, kk), rl(cur.s2.y, kk), rl(cur.s2.z, kk), rl(cur.s2.w, kk),
+                                              rl(cur.s3.x, kk), rl(cur.s3.y, kk), rl(cur.s3.z, kk), rl(cur.s3.w, kk)};
 #pragma unroll
                         for (int j = 0; j < 16; ++j) {
+                            const float t = (xs[j] >= cap) ? cap : __int_as_float(0x7f800000);
                             const float e = c * 0.99f + ys[j];
                             const float m = (e < cap) ? e : cap;
-                            c = (c >= ts[j]) ? cap : m;
+                            c = (c >= t) ? cap : m;
                         }
                     }
                     full = fe;
                 } else {
+                    const float xs[16] = {rl(cur.s0.x, kk), rl(cur.s0.y, kk), rl(cur.s0.z, kk), rl(cur.s0.w, kk), rl(cur.s1.x, kk), rl(cur.s1.y, kk),
+                                          rl(cur.s1.z, kk), rl(cur.s1.w, kk), rl(cur.s2.x, kk), rl(cur.s2.y, kk), rl(cur.s2.z, kk), rl(cur.s2.w, kk),
+                                          rl(cur.s3.x, kk), rl(cur.s3.y, kk), rl(cur.s3.z, kk), rl(cur.s3.w, kk)};
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         full = ema99(full, xs[j]);
