@@ -151,33 +151,43 @@ __device__ __forceinline__ float wave_shr1(const float v, const float first) {
 // and it holds nf anyway), so its DPP writes are dropped (bound_ctrl:0) and it keeps the pre-set values for input nf.
 // The two s_nop cover the VALU-write -> DPP-read hazard (2 wait states), which the compiler cannot see inside asm.
 #define NF_DPP " wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define NF_X4(P) P P P P
+// Extra passes leave settled lanes unchanged, so the pass count is rounded up to the unrolled body (4 passes per asm block).
+#define NF_PASS_MIN                             \
+    "s_nop 1\n"                                 \
+    "v_min_f32_dpp %1, %0, %4" NF_DPP           \
+    "v_mul_f32_dpp %2, %0, %5" NF_DPP           \
+    "v_mul_f32 %3, %6, %1\n"                    \
+    "v_add_f32 %0, %2, %3\n"                    \
+    "v_add_f32 %0, 0x358637bd, %0\n"
+#define NF_PASS_SELF                            \
+    "s_nop 1\n"                                 \
+    "v_mul_f32_dpp %1, %0, %3" NF_DPP           \
+    "v_mul_f32_dpp %2, %0, %4" NF_DPP           \
+    "v_add_f32 %0, %1, %2\n"                    \
+    "v_add_f32 %0, 0x358637bd, %0\n"
+#define NF_PASS_SCALED                          \
+    "s_nop 1\n"                                 \
+    "v_mul_f32_dpp %1, %0, %4" NF_DPP           \
+    "v_min_f32_dpp %1, %0, %1" NF_DPP           \
+    "v_mul_f32_dpp %2, %0, %5" NF_DPP           \
+    "v_mul_f32 %3, %6, %1\n"                    \
+    "v_add_f32 %0, %2, %3\n"                    \
+    "v_add_f32 %0, 0x358637bd, %0\n"
 __device__ __forceinline__ float nf_chain_min(const float nf, const float operand, const int passes) {
     const float k97 = 0.97f, k03 = static_cast<float>(1.0 - static_cast<double>(0.97f));
     float v = nf, m, a = nf * k97, b;
     asm volatile("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(operand), "v"(nf));
-    for (int t = 0; t < passes; ++t)
-        asm volatile("s_nop 1\n"
-                     "v_min_f32_dpp %1, %0, %4" NF_DPP
-                     "v_mul_f32_dpp %2, %0, %5" NF_DPP
-                     "v_mul_f32 %3, %6, %1\n"
-                     "v_add_f32 %0, %2, %3\n"
-                     "v_add_f32 %0, 0x358637bd, %0"
-                     : "+v"(v), "+v"(m), "+v"(a), "=&v"(b)
-                     : "v"(operand), "v"(k97), "v"(k03));
+    for (int t = 0; t < passes; t += 4)
+        asm volatile(NF_X4(NF_PASS_MIN) : "+v"(v), "+v"(m), "+v"(a), "=&v"(b) : "v"(operand), "v"(k97), "v"(k03));
     return v;
 }
 // operand_j = the chain value itself (capped_ == cap >= noise floor): min() is the identity
 __device__ __forceinline__ float nf_chain_self(const float nf, const int passes) {
     const float k97 = 0.97f, k03 = static_cast<float>(1.0 - static_cast<double>(0.97f));
     float v = nf, a = nf * k97, b = nf * k03;
-    for (int t = 0; t < passes; ++t)
-        asm volatile("s_nop 1\n"
-                     "v_mul_f32_dpp %1, %0, %3" NF_DPP
-                     "v_mul_f32_dpp %2, %0, %4" NF_DPP
-                     "v_add_f32 %0, %1, %2\n"
-                     "v_add_f32 %0, 0x358637bd, %0"
-                     : "+v"(v), "+v"(a), "+v"(b)
-                     : "v"(k97), "v"(k03));
+    for (int t = 0; t < passes; t += 4)
+        asm volatile(NF_X4(NF_PASS_SELF) : "+v"(v), "+v"(a), "+v"(b) : "v"(k97), "v"(k03));
     return v;
 }
 // operand_j = scale * chain value with scale < 1 (an SNR threshold below 0 dB)
@@ -185,16 +195,8 @@ __device__ __forceinline__ float nf_chain_scaled(const float nf, const float sca
     const float k97 = 0.97f, k03 = static_cast<float>(1.0 - static_cast<double>(0.97f));
     float v = nf, a = nf * k97, m = nf * scale, b;
     asm volatile("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(nf));
-    for (int t = 0; t < passes; ++t)
-        asm volatile("s_nop 1\n"
-                     "v_mul_f32_dpp %1, %0, %4" NF_DPP
-                     "v_min_f32_dpp %1, %0, %1" NF_DPP
-                     "v_mul_f32_dpp %2, %0, %5" NF_DPP
-                     "v_mul_f32 %3, %6, %1\n"
-                     "v_add_f32 %0, %2, %3\n"
-                     "v_add_f32 %0, 0x358637bd, %0"
-                     : "+v"(v), "+v"(m), "+v"(a), "=&v"(b)
-                     : "v"(scale), "v"(k97), "v"(k03));
+    for (int t = 0; t < passes; t += 4)
+        asm volatile(NF_X4(NF_PASS_SCALED) : "+v"(v), "+v"(m), "+v"(a), "=&v"(b) : "v"(scale), "v"(k97), "v"(k03));
     return v;
 }
 
