@@ -226,6 +226,17 @@ __device__ __forceinline__ int trailing_ones_from(const unsigned long long okmas
     return (~m == 0ull) ? 64 - kk : __ffsll(static_cast<long long>(~m)) - 1;
 }
 
+// 16 samples of the bare EMA c' = c*0.99 + y (y = x*0.01 already formed): the value after the block and the largest value seen
+__device__ __forceinline__ void ema_trial(const float (&ys)[16], const float c, float& cs, float& emax) {
+    cs = c, emax = c;
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const float c1 = cs * 0.99f + ys[j];
+        cs = c1 * 0.99f + ys[j + 1];
+        emax = fmaxf(fmaxf(emax, c1), cs);
+    }
+}
+
 __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
     const int r = blockIdx.x;
     const int row = a.rows[r];
@@ -314,7 +325,8 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                 t.nf = nf, t.cap = cap, t.c = c, t.full = full;
                 core[blk / bps] = t;
             }
-            const float fe = rl(cur.fe, kk), fm = rl(cur.fm, kk), x0 = rl(cur.x0, kk), xm = rl(cur.xm, kk);
+            float fe = rl(cur.fe, kk);
+            const float fm = rl(cur.fm, kk), x0 = rl(cur.x0, kk), xm = rl(cur.xm, kk);
             // squelch.cpp:212-214: the noise floor moves on the first sample of each block, from capped_ of the previous sample
             nf = noise_floor_step(nf, c);
             cap = cap_of(p, nf);
@@ -345,15 +357,36 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                         ys[j] = rl(yv[j], kk);
                     // Trial: the cap does not bind anywhere in the block (the decay after a burst).  Then capped_ is the
                     // bare EMA, two operations per sample; accepted iff every value stayed below the cap.
-                    float cs = c, emax = c;
-#pragma unroll
-                    for (int j = 0; j < 16; j += 2) {
-                        const float c1 = cs * 0.99f + ys[j];
-                        cs = c1 * 0.99f + ys[j + 1];
-                        emax = fmaxf(fmaxf(emax, c1), cs);
-                    }
+                    float cs, emax;
+                    ema_trial(ys, c, cs, emax);
                     if (emax < cap) {
                         c = cs;
+                        // Decay run: while capped_ has not met full_ again the following blocks have to be stepped too.
+                        // Stay here for them (noise floor step, cap, trial) instead of going round the hypothesis logic;
+                        // a block whose trial fails is left to the general path, which is exact for any block.
+                        float fe_k = fe;
+                        while (kk + 1 < nb && c != fe_k) {
+                            const int k1 = kk + 1;
+                            if (!(rl(cur.fm, k1) >= 0.0f))
+                                break;
+                            if ((g0 + k1) % bps == 0 && lane == 0) {
+                                TpCore t;
+                                t.nf = nf, t.cap = cap, t.c = c, t.full = fe_k;
+                                core[(g0 + k1) / bps] = t;
+                            }
+                            const float nf1 = noise_floor_step(nf, c);
+                            const float cap1 = cap_of(p, nf1);
+#pragma unroll
+                            for (int j = 0; j < 16; ++j)
+                                ys[j] = rl(yv[j], k1);
+                            ema_trial(ys, c, cs, emax);
+                            if (!(emax < cap1))
+                                break;
+                            nf = nf1, cap = cap1, c = cs, kk = k1;
+                            fe_k = rl(cur.fe, k1);
+                            ++n_step;
+                        }
+                        fe = fe_k;
                     } else {
                         // capped_step() with the shortcut "c >= cap && x >= cap" as "c >= t", t = cap where x >= cap, +inf elsewhere
                         const float xs[16] = {rl(cur.s0.x, kk), rl(cur.s0.y, kk), rl(cur.s0.z, kk), rl(cur.s0.w, kk), rl(cur.s1.x, kk), rl(cur.s1.y, kk),
