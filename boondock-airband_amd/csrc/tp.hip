@@ -39,6 +39,8 @@
 
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 namespace mi {
 namespace {
 
@@ -131,14 +133,10 @@ __global__ __launch_bounds__(64) void k_tp_full(const TpArgs a) {
 // =====================================================================================================
 // A: the exact core chain, one wave per channel
 // =====================================================================================================
-// wave-uniform lane read / write (v_readlane_b32 / v_writelane_b32: no LDS round trip)
+// wave-uniform lane read (v_readlane_b32: no LDS round trip)
 __device__ __forceinline__ float rl(const float v, const int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
-__device__ __forceinline__ float wl(const float vec, const float val, const int lane) {
-    return (static_cast<int>(threadIdx.x) == lane) ? val : vec;  // v_cmp + v_cndmask with a scalar lane index
-}
-
 // lane j <- lane j-1, lane 0 <- `first` (DPP wave_shr:1, all lanes take part: call it from uniform control flow only)
 __device__ __forceinline__ float wave_shr1(const float v, const float first) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xf, 0xf, false));
@@ -550,10 +548,17 @@ __device__ __forceinline__ float tp_step(TpLane& s, const ChanParams& p, const u
     }
     // ---- AM edges, rtl_airband.cpp:554-569 ----
     if (s.cur != SQ_OPEN && s.next == SQ_OPEN) {  // first_open_sample: bootstrap agcavgfast
-        for (int kk = 0; kk < kAgcExtra; ++kk) {
-            const float w = magrow[i + kk];
-            if (w >= s.level)
-                s.agc = s.agc * 0.9f + w * 0.1f;
+        static_assert(kAgcExtra % 25 == 0, "bootstrap batches");
+#pragma unroll 1
+        for (int k0 = 0; k0 < kAgcExtra; k0 += 25) {  // 25 independent loads in flight, then the serial average
+            float w[25];
+#pragma unroll
+            for (int j = 0; j < 25; ++j)
+                w[j] = magrow[i + k0 + j];
+#pragma unroll
+            for (int j = 0; j < 25; ++j)
+                if (w[j] >= s.level)
+                    s.agc = s.agc * 0.9f + w[j] * 0.1f;
         }
         if (in_seg)
             s.uses_agc = 1;
@@ -693,11 +698,13 @@ __device__ __forceinline__ void tp_chunk(TpLane& s, const ChanParams& p, const T
             }
         }
     } else {
-        // general path (rare): one copy of the full step, samples re-read from the (L1-resident) plane
+        // general path (rare): one copy of the full step
         float wv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {
-            const float wk = tp_step(s, p, i + k, magrow[kAgcExtra + i + k], magrow[i + k], magrow, in_seg, batch0, ev_slot, ev_stride);
+            const float xk = (k == 0) ? xv[0] : (k == 1) ? xv[1] : (k == 2) ? xv[2] : xv[3];  // in registers already
+            const float ak = (k == 0) ? av[0] : (k == 1) ? av[1] : (k == 2) ? av[2] : av[3];
+            const float wk = tp_step(s, p, i + k, xk, ak, magrow, in_seg, batch0, ev_slot, ev_stride);
             wv[0] = (k == 0) ? wk : wv[0];
             wv[1] = (k == 1) ? wk : wv[1];
             wv[2] = (k == 2) ? wk : wv[2];
@@ -709,30 +716,252 @@ __device__ __forceinline__ void tp_chunk(TpLane& s, const ChanParams& p, const T
         out_store4(a, row, i, w);
 }
 
-// run steps [i0, i1) (multiples of 16); writes audio when in_seg.  Sixteen steps of input per lane are requested
-// while the previous sixteen are processed.
-__device__ __forceinline__ void tp_run(TpLane& s, const ChanParams& p, const TpArgs& a, const int row, const float* __restrict__ magrow,
-                                       const uint32_t i0, const uint32_t i1, const bool in_seg, const uint32_t batch0, const size_t rec_idx) {
+// ---- sixteen steps i .. i+15 (one squelch block) ----
+// The wide lanes are issue bound like the core wave, so whole blocks are settled from the block aggregates of k_tp_full
+// wherever the state machine cannot move:
+//   capped_ over the block   MERGED (CLOSED only: just the maximum is known), SATURATED, or the bare-EMA trial (max and min)
+//   low_signal_count_        stays 0 when no sample of the block is below the level, else counted sample by sample
+//   CLOSED/CLOSED   max capped_ < level                                  -> closed_sample_count_ (+ the flap reset), audio 0
+//   OPEN/OPEN       min capped_ >= level, low count < 88                  -> AGC + audio
+//   OPENING/OPENING, CLOSING/CLOSING, LSA/LSA: delay_ does not run out    -> delay_ += 16 (+ AGC + audio while CLOSING)
+// Any other block goes through tp_chunk() four times from the untouched state.
+struct BlkAgg {
+    float fe, fm, x0, xm;
+};
+__device__ __forceinline__ BlkAgg agg_load(const TpArgs& a, const size_t idx) {
+    BlkAgg g;
+    g.fe = a.blk_fe[idx], g.fm = a.blk_fm[idx], g.x0 = a.blk_x0[idx], g.xm = a.blk_xm[idx];
+    return g;
+}
+struct BlkSamples {  // squelch samples (magrow[100 + i ..]) and audio samples (magrow[i ..]); named members: arrays end up in scratch
+    float4 x0, x1, x2, x3, a0, a1, a2, a3;
+};
+__device__ __forceinline__ BlkSamples samples_load(const float* __restrict__ magrow, const uint32_t i) {
+    BlkSamples q;
+    const float4* __restrict__ xp = reinterpret_cast<const float4*>(magrow + kAgcExtra + i);
+    const float4* __restrict__ ap = reinterpret_cast<const float4*>(magrow + i);
+    q.x0 = xp[0], q.x1 = xp[1], q.x2 = xp[2], q.x3 = xp[3];
+    q.a0 = ap[0], q.a1 = ap[1], q.a2 = ap[2], q.a3 = ap[3];
+    return q;
+}
+
+// rtl_airband.cpp:574-641 with is_open() true, for one sample; returns waveout
+template <bool kAudio>
+__device__ __forceinline__ float agc_audio(TpLane& s, const ChanParams& p, const float x, const float aud, const float level) {
+    if (x > level)
+        s.agc = s.agc * 0.995f + x * 0.005f;
+    // The AGC clip feedback (rtl_airband.cpp:580-584) puts the correctly rounded division on the serial chain.  Its
+    // outcome |waveout| > 0.8 is decided by comparing |num| with 0.79 den and 0.81 den (each exact to 2e-7) unless the
+    // quotient is within 1 % of the threshold; the exact quotient is still the audio sample (not formed at all while
+    // warming up).  A den that is not a positive number fails both comparisons and takes the exact path.
+    const float num = aud - s.agc, den = s.agc * 1.5f;
+    const float an = fabsf(num);
+    bool clip = an > den * 0.81f;
+    if (!(an < den * 0.79f) && !clip)
+        clip = fabsf(num / den) > 0.8f;
+    if (clip)
+        s.agc *= 1.15f;
+    if (!kAudio)
+        return 0.0f;
+    float wout = num / den;
+    if (clip)
+        wout *= 0.85f;
+    wout *= p.ampfactor;
+    if (wout != wout)
+        wout = 0.0f;
+    else if (wout > 1.0f)
+        wout = 1.0f;
+    else if (wout < -1.0f)
+        wout = -1.0f;
+    return wout;
+}
+
+// agc_audio() over the 16 samples of a block without a branch per sample (a lone wave pays dearly for the scalar side of a
+// divergent branch): the clip decisions come from the two comparisons alone and `amb` records whether any |num| fell between
+// 0.79 den and 0.81 den.  Returns false in that case (nothing is committed; the caller takes the general path for the block).
+template <bool kAudio>
+__device__ __forceinline__ bool agc_block(float& agc_io, const ChanParams& p, const float (&xs)[16], const float (&as)[16], const float level,
+                                          float (&wv)[16]) {
+    float agc = agc_io, amb = -1.0f;
+    float nums[16], dens[16], cfs[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float upd = agc * 0.995f + xs[j] * 0.005f;
+        agc = (xs[j] > level) ? upd : agc;
+        const float num = as[j] - agc, den = agc * 1.5f;
+        const float an = fabsf(num);
+        const float lo = den * 0.79f, hi = den * 0.81f;
+        amb = fmaxf(amb, fminf(an - lo, hi - an));  // >= 0 iff lo <= an <= hi
+        const bool clip = an > hi;
+        agc = clip ? agc * 1.15f : agc;
+        nums[j] = num, dens[j] = den, cfs[j] = clip ? 0.85f : 1.0f;
+    }
+    if (!(amb < 0.0f && agc > 0.0f && agc < 3.0e38f))
+        return false;
+    agc_io = agc;
+    if (kAudio) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float wout = (nums[j] / dens[j]) * cfs[j];  // x * 1.0f is x
+            wout *= p.ampfactor;
+            if (wout != wout)
+                wout = 0.0f;
+            else if (wout > 1.0f)
+                wout = 1.0f;
+            else if (wout < -1.0f)
+                wout = -1.0f;
+            wv[j] = wout;
+        }
+    }
+    return true;
+}
+
+template <bool kInSeg>
+__device__ __forceinline__ void tp_block(TpLane& s, const ChanParams& p, const TpArgs& a, const int row, const float* __restrict__ magrow,
+                                         const uint32_t i, const BlkAgg g, BlkSamples q, const bool have, const uint32_t batch0,
+                                         int* __restrict__ ev_slot, const size_t ev_stride) {
+    const float nf1 = noise_floor_step(s.nf, s.c);
+    const float cap1 = cap_of(p, nf1);
+    const float level1 = level_of(p, nf1, s.recent);
+    const bool valid = g.fm >= 0.0f;
+    const bool same_state = s.cur == s.next;
+    // ---- CLOSED and merged: nothing but the aggregates is needed ----
+    if (same_state && s.cur == SQ_CLOSED && valid && s.c == s.full && s.c < cap1 && g.fm < cap1 && g.fm < level1) {
+        s.nf = nf1, s.cap = cap1, s.level = level1, s.c = g.fe, s.full = g.fe;
+        // squelch.cpp:442-449 sixteen times; the reset fires at a step that starts with the count at 1000.  It only
+        // raises the level (normal >= flappy ratio), so the block stays quiet under the new level as well.
+        if (s.closed + 15 >= kRecent && s.recent != 0) {
+            s.recent = 0;
+            s.level = level_of(p, s.nf, 0);
+        }
+        s.closed = min(s.closed + 16, kRecent);
+        if (kInSeg) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                out_store4(a, row, i + 4 * k, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        return;
+    }
+    if (!have)
+        q = samples_load(magrow, i);
+    const float xs[16] = {q.x0.x, q.x0.y, q.x0.z, q.x0.w, q.x1.x, q.x1.y, q.x1.z, q.x1.w,
+                          q.x2.x, q.x2.y, q.x2.z, q.x2.w, q.x3.x, q.x3.y, q.x3.z, q.x3.w};
+    bool settled = false;
+    if (same_state && valid) {
+        // ---- capped_ over the block ----
+        float c_end = 0.f, cmax = 0.f, cmin = 0.f;
+        bool c_ok = false;
+        if (capped_step(s.c, g.x0, cap1) == cap1 && g.xm >= cap1) {  // SATURATED
+            c_end = cmax = cmin = cap1;
+            c_ok = true;
+        } else {  // the cap does not bind anywhere: bare EMA
+            const float nfac = static_cast<float>(1.0 - static_cast<double>(0.99f));
+            float cs = s.c;
+            cmax = cmin = 0.f;
+            float emax = 0.f, emin = 3.4e38f;  // of capped_ after each sample (what the state machine compares)
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                const float c1 = cs * 0.99f + xs[j] * nfac;
+                cs = c1 * 0.99f + xs[j + 1] * nfac;
+                emax = fmaxf(fmaxf(emax, c1), cs);
+                emin = fminf(fminf(emin, c1), cs);
+            }
+            c_end = cs, cmax = emax, cmin = emin;
+            c_ok = emax < cap1 && !(s.c >= cap1 && xs[0] >= cap1);  // squelch.cpp:509-510 never takes the cap
+        }
+        // ---- low_signal_count_ over the block (squelch.cpp:236-244; not counted in CLOSED and LOW_SIGNAL_ABORT) ----
+        int low = s.low, lowmax = 0;
+        const bool counts = s.cur != SQ_CLOSED && s.cur != SQ_LSA;
+        if (counts) {
+            if (g.x0 >= level1 && g.xm >= level1) {
+                low = 0;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    low = (xs[j] >= level1) ? 0 : low + 1;
+                    lowmax = max(lowmax, low);
+                }
+            }
+        }
+        const bool low_ok = lowmax < kLowSignalAbort;
+        const bool quiet = s.cur == SQ_CLOSED && cmax < level1;
+        const bool steady_open = s.cur == SQ_OPEN && cmin >= level1 && low_ok;
+        const bool wait_opening = s.cur == SQ_OPENING && s.delay + 16 < kOpenDelay && low_ok;
+        const bool wait_closing = s.cur == SQ_CLOSING && s.delay + 16 < kCloseDelay && low_ok;
+        const bool wait_lsa = s.cur == SQ_LSA && s.delay + 16 < kCloseDelay;
+        bool ok = c_ok && (quiet || steady_open || wait_opening || wait_closing || wait_lsa);
+        float wv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            wv[j] = 0.f;
+        float agc = s.agc;
+        if (ok && (steady_open || wait_closing)) {  // still open: rtl_airband.cpp:574-641
+            const float as[16] = {q.a0.x, q.a0.y, q.a0.z, q.a0.w, q.a1.x, q.a1.y, q.a1.z, q.a1.w,
+                                  q.a2.x, q.a2.y, q.a2.z, q.a2.w, q.a3.x, q.a3.y, q.a3.z, q.a3.w};
+            ok = agc_block<kInSeg>(agc, p, xs, as, level1, wv);
+        }
+        if (ok) {
+            settled = true;
+            s.nf = nf1, s.cap = cap1, s.level = level1, s.c = c_end, s.full = g.fe;
+            if (quiet) {
+                if (s.closed + 15 >= kRecent && s.recent != 0) {
+                    s.recent = 0;
+                    s.level = level_of(p, s.nf, 0);
+                }
+                s.closed = min(s.closed + 16, kRecent);
+            } else if (wait_lsa) {
+                s.delay += 16;
+            } else {
+                s.low = low;
+                if (!steady_open)
+                    s.delay += 16;
+                if (!wait_opening) {
+                    s.agc = agc;
+                    if (kInSeg) {
+                        s.open_mask |= ((i / kWaveBatch) == batch0) ? 1 : 2;  // 2000 = 125 blocks: a block lies in one batch
+                        s.uses_agc = 1;
+                    }
+                }
+            }
+            if (kInSeg) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    out_store4(a, row, i + 4 * k, make_float4(wv[4 * k], wv[4 * k + 1], wv[4 * k + 2], wv[4 * k + 3]));
+            }
+        }
+    }
+    if (!settled) {
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {  // one copy of tp_chunk(); selects, not indexing, keep the samples in registers
+            const float4 xk = (k == 0) ? q.x0 : (k == 1) ? q.x1 : (k == 2) ? q.x2 : q.x3;
+            const float4 ak = (k == 0) ? q.a0 : (k == 1) ? q.a1 : (k == 2) ? q.a2 : q.a3;
+            tp_chunk(s, p, a, row, magrow, i + 4 * k, xk, ak, kInSeg, batch0, ev_slot, ev_stride);
+        }
+    }
+}
+
+// run steps [i0, i1) (multiples of 16); writes audio when in_seg.  The next block's aggregates are always requested a
+// block ahead; its samples only when the lane does not expect to settle it from the aggregates alone.
+template <bool kInSeg>
+__device__ __forceinline__ void tp_run(TpLane& s, const ChanParams& p, const TpArgs& a, const int r, const int row,
+                                       const float* __restrict__ magrow, const uint32_t i0, const uint32_t i1, const uint32_t batch0,
+                                       const size_t rec_idx) {
     if (i0 >= i1)
         return;
     int* __restrict__ ev_slot = a.rec + 19 * a.rec_stride + rec_idx;
     const size_t ev_stride = a.rec_stride;
-    const float4* __restrict__ xp = reinterpret_cast<const float4*>(magrow + kAgcExtra);
-    const float4* __restrict__ ap = reinterpret_cast<const float4*>(magrow);
-    uint32_t q = i0 >> 2;
-    float4 x0 = xp[q], x1 = xp[q + 1], x2 = xp[q + 2], x3 = xp[q + 3];
-    float4 a0 = ap[q], a1 = ap[q + 1], a2 = ap[q + 2], a3 = ap[q + 3];
+    const size_t bbase = static_cast<size_t>(r) * a.nblk;
+    BlkAgg gn = agg_load(a, bbase + (i0 >> 4));
+    BlkSamples qn = samples_load(magrow, i0);
     for (uint32_t i = i0; i < i1; i += 16) {
-        const float4 cx0 = x0, cx1 = x1, cx2 = x2, cx3 = x3, ca0 = a0, ca1 = a1, ca2 = a2, ca3 = a3;
+        const BlkAgg g = gn;
+        const BlkSamples q = qn;
+        const bool have = true;
         if (i + 16 < i1) {
-            q = (i + 16) >> 2;
-            x0 = xp[q], x1 = xp[q + 1], x2 = xp[q + 2], x3 = xp[q + 3];
-            a0 = ap[q], a1 = ap[q + 1], a2 = ap[q + 2], a3 = ap[q + 3];
+            gn = agg_load(a, bbase + ((i + 16) >> 4));
+            qn = samples_load(magrow, i + 16);
         }
-        tp_chunk(s, p, a, row, magrow, i, cx0, ca0, in_seg, batch0, ev_slot, ev_stride);
-        tp_chunk(s, p, a, row, magrow, i + 4, cx1, ca1, in_seg, batch0, ev_slot, ev_stride);
-        tp_chunk(s, p, a, row, magrow, i + 8, cx2, ca2, in_seg, batch0, ev_slot, ev_stride);
-        tp_chunk(s, p, a, row, magrow, i + 12, cx3, ca3, in_seg, batch0, ev_slot, ev_stride);
+        tp_block<kInSeg>(s, p, a, row, magrow, i, g, q, have, batch0, ev_slot, ev_stride);
     }
 }
 
@@ -771,7 +1000,7 @@ __device__ __forceinline__ void load_core(TpLane& s, const ChanParams& p, const 
 }
 
 __global__ __launch_bounds__(64) void k_tp_seg(const TpArgs a) {
-    const int gid = blockIdx.x * 64 + threadIdx.x;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // blockDim.x = lanes per wave (see launch_tp_back)
     const int nsc = static_cast<int>(a.seg1 - a.seg0);  // segments of this chunk
     if (gid >= a.nrows * nsc)
         return;
@@ -796,11 +1025,11 @@ __global__ __launch_bounds__(64) void k_tp_seg(const TpArgs a) {
         s.agc = 0.5f;
     }
     load_core(s, p, a.core[static_cast<size_t>(r) * (a.nseg + 1) + wk]);
-    tp_run(s, p, a, row, magrow, wk * TP_L, s0, false, 0, static_cast<size_t>(r) * a.nseg + k);
+    tp_run<false>(s, p, a, r, row, magrow, wk * TP_L, s0, 0, static_cast<size_t>(r) * a.nseg + k);
     const TpFsm S = canon(s);
     const float s_agc = s.agc;
     seg_reset(s);
-    tp_run(s, p, a, row, magrow, s0, s1, true, s0 / kWaveBatch, static_cast<size_t>(r) * a.nseg + k);
+    tp_run<true>(s, p, a, r, row, magrow, s0, s1, s0 / kWaveBatch, static_cast<size_t>(r) * a.nseg + k);
     rec_store(a, static_cast<size_t>(r) * a.nseg + k, S, s_agc, s);
 }
 
@@ -951,7 +1180,7 @@ __device__ __forceinline__ void rerun_chain(const TpArgs& a, const int r, const 
         const TpFsm S = canon(s);
         const float s_agc = s.agc;
         seg_reset(s);
-        tp_run(s, p, a, row, magrow, s0, s1, true, s0 / kWaveBatch, base + k);
+        tp_run<true>(s, p, a, r, row, magrow, s0, s1, s0 / kWaveBatch, base + k);
         rec_store(a, base + k, S, s_agc, s);
     }
 }
@@ -1138,7 +1367,14 @@ hipError_t launch_tp_back(const TpArgs& a_in, hipStream_t s, hipEvent_t* marks) 
     if (a.nrows == 0 || a.step1 <= a.step0)
         return hipSuccess;
     const int lanes = a.nrows * static_cast<int>(a.seg1 - a.seg0);
-    TP_LAUNCH(k_tp_seg, (lanes + 63) / 64, 64);
+    // Lanes of one wave sit at different points of the capture, so a wave pays for every path one of its lanes takes.
+    // There are far fewer lanes than the 1024 SIMDs x 64: spread them thin (few lanes per wave) to cut the divergence.
+    static const int lpw = [] {
+        const char* e = std::getenv("MI_AIRBAND_TP_LPW");
+        const int v = e ? std::atoi(e) : 64;
+        return (v >= 1 && v <= 64) ? v : 64;
+    }();
+    TP_LAUNCH(k_tp_seg, (lanes + lpw - 1) / lpw, lpw);
     TP_MARK(0);
     for (int round = 0; round < 2; ++round) {
         a.scan_round = round;
