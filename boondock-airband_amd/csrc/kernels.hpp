@@ -141,8 +141,9 @@ constexpr uint32_t TP_CHUNK_UNIT = 64000;  // lcm(TP_L = 512, WAVE_BATCH = 2000)
 // One chunk in three parts so the caller can put the serial part on its own stream:
 hipError_t launch_tp_front(const TpArgs& a, hipStream_t s);                        // (prologue on the first chunk) + k_tp_full
 hipError_t launch_tp_core(const TpArgs& a, hipStream_t s);                         // k_tp_core
-hipError_t launch_tp_back(const TpArgs& a, hipStream_t s, hipEvent_t* marks);      // k_tp_seg ... k_tp_finish; marks[0..4] optional
-constexpr int TP_BACK_MARKS = 4;  // marks: after seg, after scan#0, after fix#0, after finish
+hipError_t launch_tp_seg(const TpArgs& a, hipStream_t s);                          // k_tp_seg (needs core(i) only)
+hipError_t launch_tp_rest(const TpArgs& a, hipStream_t s, hipEvent_t* marks);      // k_tp_scan ... k_tp_finish (needs seg(i) and rest(i-1))
+constexpr int TP_REST_MARKS = 3;  // marks (optional): after scan#0, after fix#0, after finish
 
 
 hipError_t launch_channelize(const ChannelizeArgs& a, int log2n, int sfmt, int nstreams, hipStream_t s);

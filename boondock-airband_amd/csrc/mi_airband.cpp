@@ -59,9 +59,10 @@ struct mi_demod {
     size_t plane_stride = 0;
     hipStream_t own_stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    static constexpr int kMaxChunks = 64, kEvPerChunk = 10;
+    static constexpr int kMaxChunks = 64, kEvPerChunk = 11, kSegStreams = 2;
     std::vector<hipEvent_t> chunk_ev;  // per chunk: stage1 begin/end, full end, core begin/end, back begin, seg/scan0/fix0/finish ends
     hipStream_t aux_stream = nullptr;  // carries the serial core chain of the time-parallel path
+    hipStream_t seg_stream[kSegStreams] = {nullptr, nullptr};  // the speculative segment passes (need core(i) only)
     int tp_chunks = 0;
     mi::TpCore* d_core_carry = nullptr;
     float* d_full0 = nullptr;
@@ -274,26 +275,28 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             HIP_TRY(hipEventRecord(ev(i, 2), s));
             return MI_OK;
         };
+        for (int i = 0; i < C; ++i) {  // stage 1 + aggregates of every chunk first: nothing else feeds them
+            int rc = front(i);
+            if (rc != MI_OK)
+                return rc;
+        }
         for (int i = 0; i < C; ++i) {
-            if (i == 0) {
-                int rc = front(0);
-                if (rc != MI_OK)
-                    return rc;
-            }
-            if (i + 1 < C) {
-                int rc = front(i + 1);
-                if (rc != MI_OK)
-                    return rc;
-            }
             const mi::TpArgs c = chunk(i);
             HIP_TRY(hipStreamWaitEvent(h->aux_stream, ev(i, 2), 0));
             HIP_TRY(hipEventRecord(ev(i, 3), h->aux_stream));
             HIP_TRY(mi::launch_tp_core(c, h->aux_stream));
             HIP_TRY(hipEventRecord(ev(i, 4), h->aux_stream));
-            HIP_TRY(hipStreamWaitEvent(s, ev(i, 4), 0));
-            HIP_TRY(hipEventRecord(ev(i, 5), s));
-            hipEvent_t marks[mi::TP_BACK_MARKS] = {ev(i, 6), ev(i, 7), ev(i, 8), ev(i, 9)};
-            HIP_TRY(mi::launch_tp_back(c, s, marks));
+            hipStream_t ss = h->seg_stream[i % mi_demod::kSegStreams];
+            if (i < mi_demod::kSegStreams)
+                HIP_TRY(hipStreamWaitEvent(ss, h->ev[1], 0));  // not before the work queued ahead of this call
+            HIP_TRY(hipStreamWaitEvent(ss, ev(i, 4), 0));
+            HIP_TRY(hipEventRecord(ev(i, 5), ss));
+            HIP_TRY(mi::launch_tp_seg(c, ss));
+            HIP_TRY(hipEventRecord(ev(i, 6), ss));
+            HIP_TRY(hipStreamWaitEvent(s, ev(i, 6), 0));
+            HIP_TRY(hipEventRecord(ev(i, 10), s));
+            hipEvent_t marks[mi::TP_REST_MARKS] = {ev(i, 7), ev(i, 8), ev(i, 9)};
+            HIP_TRY(mi::launch_tp_rest(c, s, marks));
         }
         h->tp_chunks = C;
     } else {
@@ -344,6 +347,9 @@ void mi_demod_destroy(mi_demod* h) {
             (void)hipEventDestroy(e);
     if (h->aux_stream)
         (void)hipStreamDestroy(h->aux_stream);
+    for (hipStream_t ss : h->seg_stream)
+        if (ss)
+            (void)hipStreamDestroy(ss);
     if (h->own_stream)
         (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -403,6 +409,8 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     for (auto& ev : h->ev)
         TRY_OR_BAIL(hipEventCreate(&ev));
     TRY_OR_BAIL(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    for (hipStream_t& ss : h->seg_stream)
+        TRY_OR_BAIL(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
     const size_t rows = static_cast<size_t>(h->rows);
     TRY_OR_BAIL(dalloc(&h->d_window, p.window.size()));
     TRY_OR_BAIL(dalloc(&h->d_tw, p.tw.size()));
@@ -705,10 +713,10 @@ int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms_to
         nm = index == 0 ? "k_channelize" : "k_demod";
         HIP_TRY(hipEventElapsedTime(&t, h->ev[index], h->ev[index + 1]));
     } else {
-        // per chunk events: 0 stage1 begin, 1 stage1 end, 2 k_tp_full end, 3 core begin, 4 core end, 5 back begin,
-        // 6 seg end, 7 scan#0 end, 8 fix#0 end, 9 finish end
+        // per chunk events: 0 stage1 begin, 1 stage1 end, 2 k_tp_full end, 3 core begin, 4 core end (aux stream), 5 seg begin,
+        // 6 seg end (segment stream), 10 scan#0 begin, 7 scan#0 end, 8 fix#0 end, 9 finish end
         static const char* const names[] = {"k_channelize", "k_tp_full", "k_tp_core", "k_tp_seg", "k_tp_scan#0", "k_tp_fix#0", "k_tp_rest"};
-        static const int from[] = {0, 1, 3, 5, 6, 7, 8}, to[] = {1, 2, 4, 6, 7, 8, 9};
+        static const int from[] = {0, 1, 3, 5, 10, 7, 8}, to[] = {1, 2, 4, 6, 7, 8, 9};
         if (index > 6)
             return fail(MI_ERR_INVALID, "kernel index out of range");
         nm = names[index];

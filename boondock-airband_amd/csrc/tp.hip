@@ -1000,7 +1000,7 @@ __device__ __forceinline__ void load_core(TpLane& s, const ChanParams& p, const 
 }
 
 __global__ __launch_bounds__(64) void k_tp_seg(const TpArgs a) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // blockDim.x = lanes per wave (see launch_tp_back)
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // blockDim.x = lanes per wave (see launch_tp_seg)
     const int nsc = static_cast<int>(a.seg1 - a.seg0);  // segments of this chunk
     if (gid >= a.nrows * nsc)
         return;
@@ -1362,28 +1362,34 @@ hipError_t launch_tp_core(const TpArgs& a, hipStream_t s) {
         }                                                  \
     } while (0)
 
-hipError_t launch_tp_back(const TpArgs& a_in, hipStream_t s, hipEvent_t* marks) {
-    TpArgs a = a_in;
+hipError_t launch_tp_seg(const TpArgs& a, hipStream_t s) {
     if (a.nrows == 0 || a.step1 <= a.step0)
         return hipSuccess;
     const int lanes = a.nrows * static_cast<int>(a.seg1 - a.seg0);
-    // Lanes of one wave sit at different points of the capture, so a wave pays for every path one of its lanes takes.
-    // There are far fewer lanes than the 1024 SIMDs x 64: spread them thin (few lanes per wave) to cut the divergence.
+    // Lanes of one wave sit at different points of the capture, so a wave pays for every path one of its lanes takes;
+    // MI_AIRBAND_TP_LPW spreads them over more waves (measured: no gain on MI355X, the slowest wave sets the time).
     static const int lpw = [] {
         const char* e = std::getenv("MI_AIRBAND_TP_LPW");
         const int v = e ? std::atoi(e) : 64;
         return (v >= 1 && v <= 64) ? v : 64;
     }();
     TP_LAUNCH(k_tp_seg, (lanes + lpw - 1) / lpw, lpw);
-    TP_MARK(0);
+    return hipSuccess;
+}
+
+hipError_t launch_tp_rest(const TpArgs& a_in, hipStream_t s, hipEvent_t* marks) {
+    TpArgs a = a_in;
+    if (a.nrows == 0 || a.step1 <= a.step0)
+        return hipSuccess;
+    const int lanes = a.nrows * static_cast<int>(a.seg1 - a.seg0);
     for (int round = 0; round < 2; ++round) {
         a.scan_round = round;
         TP_LAUNCH(k_tp_scan, a.nrows, 64);
         if (round == 0)
-            TP_MARK(1);
+            TP_MARK(0);
         TP_LAUNCH(k_tp_fix, (lanes + 63) / 64, 64);
         if (round == 0)
-            TP_MARK(2);
+            TP_MARK(1);
     }
     a.scan_round = 2;
     TP_LAUNCH(k_tp_scan, a.nrows, 64);
@@ -1392,7 +1398,7 @@ hipError_t launch_tp_back(const TpArgs& a_in, hipStream_t s, hipEvent_t* marks) 
     TP_LAUNCH(k_tp_scan, a.nrows, 64);
     TP_LAUNCH(k_tp_fades, (lanes + 63) / 64, 64);
     TP_LAUNCH(k_tp_finish, a.nrows, 64);
-    TP_MARK(3);
+    TP_MARK(2);
     return hipSuccess;
 }
 
