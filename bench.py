@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+PMC_PROFILE = "r01_final_pmc.csv"
 SAMPLE_RATE = 2560000
 WAVE_BATCH = 2000
 AGC_EXTRA = 100
@@ -172,6 +173,17 @@ def main():
                              "GBps": (nbytes / (ms * 1e-3) / 1e9) if ms > 0 and nbytes > 0 else None}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         achieved = kernels[dom]["GBps"]
+        # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the bench):
+        # only quoted when the launch geometry is the one that was profiled (default --seconds, default chunking).
+        traffic, traffic_src = {}, None
+        pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
+        if os.path.exists(pmc) and nbat == 512 and not args.noise_only and "MI_AIRBAND_TP_CHUNKS" not in os.environ:
+            import csv
+            for row in csv.DictReader(open(pmc)):
+                traffic[row["kernel"]] = int(row["hbm_bytes_per_launch"])
+            traffic_src = f"profiles/{PMC_PROFILE}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command, FETCH_SIZE x2 (gfx950)"
+        for name, k in kernels.items():
+            k["traffic"] = traffic.get(name.split("#")[0])
         out = {
             "metric": "IQ MS/s processed (x real-time) @ 8ch fft_size=512",
             "value": value,
@@ -191,7 +203,10 @@ def main():
                        "stage2_path": "time-parallel" if h.last_path()[0] == 1 else "serial"},
             "x_realtime_per_stream": value / world / (SAMPLE_RATE / 1e6),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None},
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": kernels[dom]["traffic"],
+                         "traffic_source": traffic_src,
+                         "note": "k_tp_core is the per-channel serial recurrence (one wave per channel): its time is set by VALU issue "
+                                 "latency of a lone wave, not by HBM; k_channelize is the kernel that streams the capture (see kernels)"},
             "kernels": kernels,
         }
         if world == 1 and args.cpu_seconds > 0:
