@@ -349,14 +349,12 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                             yv[j] = xv[j] * nfac;
                         ys_ready = true;
                     }
-                    float ys[16];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        ys[j] = rl(yv[j], kk);
                     // Trial: the cap does not bind anywhere in the block (the decay after a burst).  Then capped_ is the
-                    // bare EMA, two operations per sample; accepted iff every value stayed below the cap.
-                    float cs, emax;
-                    ema_trial(ys, c, cs, emax);
+                    // bare EMA, two operations per sample; accepted iff every value stayed below the cap.  Every lane runs
+                    // it on its own block from the common c; the stepped block's lane holds the answer (2 lane reads, not 16).
+                    float cs_l, emax_l;
+                    ema_trial(yv, c, cs_l, emax_l);
+                    float cs = rl(cs_l, kk), emax = rl(emax_l, kk);
                     if (emax < cap) {
                         c = cs;
                         // Decay run: while capped_ has not met full_ again the following blocks have to be stepped too.
@@ -374,10 +372,8 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                             }
                             const float nf1 = noise_floor_step(nf, c);
                             const float cap1 = cap_of(p, nf1);
-#pragma unroll
-                            for (int j = 0; j < 16; ++j)
-                                ys[j] = rl(yv[j], k1);
-                            ema_trial(ys, c, cs, emax);
+                            ema_trial(yv, c, cs_l, emax_l);
+                            cs = rl(cs_l, k1), emax = rl(emax_l, k1);
                             if (!(emax < cap1))
                                 break;
                             nf = nf1, cap = cap1, c = cs, kk = k1;
@@ -393,7 +389,7 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
 #pragma unroll
                         for (int j = 0; j < 16; ++j) {
                             const float t = (xs[j] >= cap) ? cap : __int_as_float(0x7f800000);
-                            const float e = c * 0.99f + ys[j];
+                            const float e = c * 0.99f + rl(yv[j], kk);
                             const float m = (e < cap) ? e : cap;
                             c = (c >= t) ? cap : m;
                         }
