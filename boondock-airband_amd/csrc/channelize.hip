@@ -255,10 +255,19 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
         if (active) {
             for (int c = tau; c < a.nch; c += TPF) {
                 const ChanParams& cp = a.cp[c];
-                const float2 v = xch[xpad(static_cast<int>(cp.bin))];
+                const uint32_t bin = a.st ? a.st[static_cast<size_t>(stream) * a.nch + c].afc_bin : cp.bin;  // dev->bins[j]
+                const float2 v = xch[xpad(static_cast<int>(bin))];
                 out_mag[c * TW + wi] = sqrtf(v.x * v.x + v.y * v.y);
                 if (cp.iq_row >= 0)
                     out_iq[cp.iq_row * TW + wi] = v;
+            }
+            // AFC reads the spectrum of the last FFT before the batch trigger (rtl_airband.cpp:648-652, square() :186-192)
+            if (a.afc_spec && w0 + static_cast<unsigned>(wi) == a.nfft - 1) {
+                float* __restrict__ sq = a.afc_spec + static_cast<size_t>(stream) * N;
+                for (int k = tau; k < N; k += TPF) {
+                    const float2 v = xch[xpad(k)];
+                    sq[k] = v.x * v.x + v.y * v.y;
+                }
             }
         }
         __syncthreads();

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
             W(kAgcExtra + i) = wout;
 
             if (++in_batch == kWaveBatch) {  // rtl_airband.cpp:523,628,667-669
-                a.axc[static_cast<size_t>(row) * a.nbatches + batch] = batch_open ? MI_SIGNAL : MI_NO_SIGNAL;
+                a.axc[static_cast<size_t>(row) * a.axc_stride + batch] = batch_open ? MI_SIGNAL : MI_NO_SIGNAL;
                 if (batch_open)
                     c.s.active_counter++;
                 batch_open = false;
@@ -544,6 +544,8 @@ __global__ void k_init_state(ChanState* st, float* carry, float* sq_ring, float*
         s.buffer_tail = 1;
         s.agcavgfast = 0.5f;    // mk_freqlist, config.cpp:280
         s.prev_waveout = 0.5f;  // config.cpp:332
+        s.afc_bin = p.bin;          // dev->bins[i] = dev->base_bins[i], config.cpp:669-670
+        s.prev_axc = MI_NO_SIGNAL;  // config.cpp:322
         st[row] = s;
     }
     for (int i = gid; i < rows * kAgcExtra; i += gsz)
@@ -591,6 +593,75 @@ hipError_t launch_demod(const DemodArgs& a, hipStream_t s) {
         return hipSuccess;
     const int blocks = (rows + a.lanes_per_wave - 1) / a.lanes_per_wave;
     hipLaunchKernelGGL(k_demod, dim3(blocks), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+namespace {
+// AFC::check<STEP> (rtl_airband.cpp:193-219) on the squared spectrum
+__device__ uint32_t afc_check(const float* __restrict__ sq, const uint32_t fft_size, const int step, const uint32_t base, const float base_value,
+                              const uint32_t afc) {
+    float threshold = 0.0f;
+    uint32_t bin;
+    for (bin = base;; bin += static_cast<uint32_t>(step)) {
+        if (step < 0) {
+            if (bin < 1u)
+                break;
+        } else if (bin + 1u >= fft_size) {
+            break;
+        }
+        const float value = sq[bin + static_cast<uint32_t>(step)];
+        if (value <= base_value)
+            break;
+        if (base == bin) {
+            threshold = (value - base_value) / static_cast<float>(afc);
+        } else {
+            if ((value - base_value) < threshold)
+                break;
+            threshold = static_cast<float>(static_cast<double>(threshold) + static_cast<double>(threshold) / 10.0);  // `threshold += threshold / 10.0`
+        }
+    }
+    return bin;
+}
+
+__global__ void k_afc(const AfcArgs a) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.nstreams * a.nch)
+        return;
+    const int stream = row / a.nch, ch = row - stream * a.nch;
+    const ChanParams& P = a.cp[ch];
+    if (P.afc == 0)
+        return;
+    ChanState& s = a.st[row];
+    char* pax = a.axc + static_cast<size_t>(row) * a.axc_stride;
+    char axc = *pax;
+    const int prev = s.prev_axc;
+    if (axc != MI_NO_SIGNAL && prev == MI_NO_SIGNAL) {
+        const float* __restrict__ sq = a.spec + static_cast<size_t>(stream) * a.fft_size;
+        const uint32_t base = P.bin;
+        const float base_value = sq[base];
+        uint32_t bin = afc_check(sq, static_cast<uint32_t>(a.fft_size), -1, base, base_value, P.afc);
+        if (bin == base)
+            bin = afc_check(sq, static_cast<uint32_t>(a.fft_size), 1, base, base_value, P.afc);
+        if (s.afc_bin != bin) {
+            s.afc_bin = bin;
+            if (bin > base)
+                axc = MI_AFC_UP;
+            else if (bin < base)
+                axc = MI_AFC_DOWN;
+            *pax = axc;
+        }
+    } else if (axc == MI_NO_SIGNAL && prev != MI_NO_SIGNAL) {
+        s.afc_bin = P.bin;
+    }
+    s.prev_axc = axc;
+}
+}  // namespace
+
+hipError_t launch_afc(const AfcArgs& a, hipStream_t s) {
+    const int rows = a.nstreams * a.nch;
+    if (rows == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_afc, dim3((rows + 63) / 64), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

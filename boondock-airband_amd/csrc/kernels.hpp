@@ -34,7 +34,9 @@ struct ChanState {
     float agcavgfast;
     float pr, pj, prev_waveout;
     uint32_t dm_phi;
-    uint32_t pad0;
+    uint32_t afc_bin;   // dev->bins[i]: the bin stage 1 picks for this channel (moved by AFC, rtl_airband.cpp:224-249)
+    int32_t prev_axc;   // channel->axcindicate left by the previous batch (what `AFC afc(dev, i)` captures, :518)
+    int32_t pad0;
     uint64_t active_counter;
     // NotchFilter x/y, LowpassFilter xv/yv (filters.h:33-61)
     float notch_x[3], notch_y[3];
@@ -58,6 +60,8 @@ struct ChannelizeArgs {
     const ChanParams* cp;
     int nch, n_iq_rows;
     unsigned* xmax;  // [nstreams*nch] running max of the magnitudes written (bit pattern; values are >= 0), or null
+    const ChanState* st;  // AFC handles: the bin of (stream, channel) is st[..].afc_bin; null: ChanParams::bin
+    float* afc_spec;      // AFC handles: [nstreams][fft_size] re^2+im^2 of the LAST window of the launch (AFC::square), or null
 };
 
 struct DemodArgs {
@@ -72,7 +76,8 @@ struct DemodArgs {
     float* carry;       // [rows][AGC_EXTRA]: lookahead carried between calls
     float2* iq_out;     // [rows][iq_out_stride] or null
     size_t iq_out_stride;
-    char* axc;          // [rows][nbatches]
+    char* axc;          // [rows][axc_stride], nbatches written
+    uint32_t axc_stride;
     const ChanParams* cp;
     ChanState* st;      // [rows]
     const float* sin_lut;  // 257
@@ -84,6 +89,17 @@ struct DemodArgs {
     int fm_quadri;
     int lanes_per_wave;
 };
+
+// AFC::finalize for one batch (rtl_airband.cpp:224-249), one thread per (stream, channel)
+struct AfcArgs {
+    int nstreams, nch, fft_size;
+    const ChanParams* cp;
+    ChanState* st;
+    const float* spec;  // [nstreams][fft_size]
+    char* axc;          // [rows][axc_stride]; entry 0 of each row is this batch
+    uint32_t axc_stride;
+};
+hipError_t launch_afc(const AfcArgs& a, hipStream_t s);
 
 // ---- time-parallel stage 2 (tp.hip) ----
 constexpr uint32_t TP_L = 512;      // steps per segment

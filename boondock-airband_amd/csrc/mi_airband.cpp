@@ -66,6 +66,7 @@ struct mi_demod {
     int tp_chunks = 0;
     mi::TpCore* d_core_carry = nullptr;
     float* d_full0 = nullptr;
+    float* d_afc_spec = nullptr;  // [nstreams][fft_size] squared spectrum of the last window of a batch (AFC handles only)
     bool ev_valid = false;
     // device memory
     float* d_window = nullptr;
@@ -172,6 +173,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     da.iq_out = d_iq_out;
     da.iq_out_stride = iq_out_stride;
     da.axc = d_axc;
+    da.axc_stride = static_cast<uint32_t>(nbatches);
     da.cp = h->d_cp;
     da.st = h->d_state;
     da.sin_lut = h->d_sin;
@@ -299,6 +301,44 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             HIP_TRY(mi::launch_tp_rest(c, s, marks));
         }
         h->tp_chunks = C;
+    } else if (h->plan.any_afc) {
+        // AFC (rtl_airband.cpp:180-251): the bins stage 1 picks in batch b+1 depend on the squelch outcome of batch b, so
+        // the batches are enqueued one at a time -- stage 1, channel loop, AFC::finalize -- with the bin table and the
+        // previous indicator resident in ChanState: no host round trip inside the call.
+        HIP_TRY(hipEventRecord(h->ev[0], s));
+        size_t f0 = 0;  // first window of the batch, relative to the call
+        for (int b = 0; b < nbatches; ++b) {
+            const bool first = h->first_call && b == 0;
+            const uint32_t nf = mi::kWaveBatch + (first ? mi::kAgcExtra : 0);
+            mi::ChannelizeArgs cb = ca;
+            cb.iq = ca.iq + f0 * ca.hop_bytes;
+            cb.valid_bytes = ca.valid_bytes - f0 * ca.hop_bytes;
+            cb.nfft = nf;
+            cb.plane_off = first ? 0 : mi::kAgcExtra;
+            cb.st = h->d_state;
+            cb.afc_spec = h->d_afc_spec;
+            HIP_TRY(mi::launch_channelize(cb, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, s));
+            if (b == 0)
+                HIP_TRY(hipEventRecord(h->ev[1], s));
+            mi::DemodArgs db = da;
+            db.nsteps = mi::kWaveBatch;
+            db.nbatches = 1;
+            db.wmain = d_wmain + static_cast<size_t>(b) * mi::kWaveBatch;
+            db.iq_out = d_iq_out ? d_iq_out + static_cast<size_t>(b) * mi::kWaveBatch : nullptr;
+            db.axc = d_axc + b;
+            HIP_TRY(mi::launch_demod(db, s));
+            mi::AfcArgs aa{};
+            aa.nstreams = h->nstreams;
+            aa.nch = h->nch;
+            aa.fft_size = h->plan.fft_size;
+            aa.cp = h->d_cp;
+            aa.st = h->d_state;
+            aa.spec = h->d_afc_spec;
+            aa.axc = d_axc + b;
+            aa.axc_stride = static_cast<uint32_t>(nbatches);
+            HIP_TRY(mi::launch_afc(aa, s));
+            f0 += nf;
+        }
     } else {
         HIP_TRY(hipEventRecord(h->ev[0], s));
         HIP_TRY(mi::launch_channelize(ca, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, s));
@@ -333,7 +373,7 @@ void mi_demod_destroy(mi_demod* h) {
     (void)hipSetDevice(h->gpu);
     void* ptrs[] = {h->d_window, h->d_tw,   h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_mag,   h->d_cplx, h->d_carry,
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc,
-                    h->d_rows,   h->d_xmax, h->d_blk_fe, h->d_blk_fm, h->d_blk_x0, h->d_blk_xm, h->d_core, h->d_rec, h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0};
+                    h->d_rows,   h->d_xmax, h->d_blk_fe, h->d_blk_fm, h->d_blk_x0, h->d_blk_xm, h->d_core, h->d_rec, h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_afc_spec};
     for (void* p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -440,8 +480,10 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     TRY_OR_BAIL(hipMemset(h->d_stats, 0, rows * sizeof(mi_channel_stats)));
     h->tp_eligible = true;
     for (const mi::ChanParams& c : p.cp)
-        if (c.modulation != MI_MOD_AM || c.needs_raw_iq || c.ctcss_enabled || c.notch_enabled)
+        if (c.modulation != MI_MOD_AM || c.needs_raw_iq || c.ctcss_enabled || c.notch_enabled || c.afc != 0)
             h->tp_eligible = false;
+    if (p.any_afc)
+        TRY_OR_BAIL(dalloc(&h->d_afc_spec, static_cast<size_t>(nstreams) * p.fft_size));
     if (h->tp_eligible) {
         h->tp_max_blk = max_steps / 16;
         h->tp_max_seg = (max_steps + mi::TP_L - 1) / mi::TP_L;

@@ -167,6 +167,7 @@ int build_plan(const mi_device_cfg& dev, const mi_channel_cfg* chans, int nch, P
     p.cp.assign(nch, ChanParams{});
     p.n_iq_rows = 0;
     p.n_ctcss_rows = 0;
+    p.any_afc = false;
     p.ctcss_coeff.clear();
     for (int i = 0; i < nch; ++i) {
         const mi_channel_cfg& k = chans[i];
@@ -175,10 +176,12 @@ int build_plan(const mi_device_cfg& dev, const mi_channel_cfg* chans, int nch, P
             *msg = "unknown modulation";  // config.cpp:344-355
             return MI_ERR_INVALID;
         }
-        if (k.afc != 0) {
-            *msg = "afc > 0 is not built yet";
-            return MI_ERR_UNSUPPORTED;
+        if (k.afc < 0 || k.afc > 255) {
+            *msg = "afc must be 0..255";  // unsigned char, config.cpp:355
+            return MI_ERR_INVALID;
         }
+        c.afc = static_cast<uint32_t>(k.afc);
+        p.any_afc = p.any_afc || k.afc != 0;
         if (k.squelch_threshold_dbfs > 0) {
             *msg = "squelch_threshold must be less than or equal to 0";  // config.cpp:447-449
             return MI_ERR_INVALID;

@@ -41,6 +41,7 @@ struct ChanParams {
     int32_t ctcss_fast_window, ctcss_slow_window;
     int32_t ctcss_fast_ndet, ctcss_slow_ndet;
     int32_t ctcss_row;  // row in the detector coefficient/state tables, -1 if none
+    uint32_t afc;       // channel_t.afc (0 = off .. 255), boondock_airband.h:258
 };
 
 struct Plan {
@@ -53,6 +54,7 @@ struct Plan {
     size_t hop_bytes = 0;  // "bps", rtl_airband.cpp:416
     int n_iq_rows = 0;     // channels with needs_raw_iq
     int n_ctcss_rows = 0;
+    bool any_afc = false;  // some channel has afc > 0: bins follow the signal, batches are processed one at a time
     std::vector<float> window;        // fft_size
     std::vector<float> tw;            // fft_size/2 x {re, im}
     std::vector<float> levels;        // 256 (u8 or s8 LUT)

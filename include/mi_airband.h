@@ -36,7 +36,7 @@ typedef enum {
     MI_ERR_NO_DEVICE = -2,   /* HIP runtime or GPU missing: the product path never falls back to CPU */
     MI_ERR_NOMEM = -3,       /* host or device allocation failed */
     MI_ERR_HIP = -4,         /* a HIP call or kernel launch failed */
-    MI_ERR_UNSUPPORTED = -5  /* valid in the reference, not built yet (afc > 0) */
+    MI_ERR_UNSUPPORTED = -5  /* valid in the reference, not built in this library */
 } mi_status;
 
 enum { MI_MOD_AM = 0, MI_MOD_NFM = 1 };                                        /* enum modulations, boondock_airband.h:202-208 */
@@ -67,7 +67,8 @@ typedef struct mi_channel_cfg {
     int bandwidth;              /* `bandwidth` Hz, 0 = none; >0 enables derotation + low-pass at bandwidth/2 */
     float ampfactor;            /* `ampfactor`, default 1 */
     int tau;                    /* channel `tau` us, <0 inherit the device's */
-    int afc;                    /* `afc` 0..255; >0 returns MI_ERR_UNSUPPORTED for now */
+    int afc;                    /* `afc` 0..255 (rtl_airband.cpp:180-251): >0 lets the picked bin follow the carrier; such a
+                                 * handle processes its batches one at a time on the device and reports MI_AFC_UP / MI_AFC_DOWN */
     int has_iq_outputs;         /* the channel has a rawfile output (config.cpp:162) */
 } mi_channel_cfg;
 
@@ -114,7 +115,8 @@ size_t mi_demod_hop_bytes(const mi_demod* h);
  *              reference's loop -- [0, nbatches*WAVE_BATCH) is what the output thread emits
  *              (output.cpp:945-950), the last AGC_EXTRA samples are the not-yet-final lookahead
  *   iq_out     [nstreams][nch][nbatches*WAVE_BATCH][2] or NULL; rows of channels without iq outputs are untouched
- *   axc        [nstreams][nch][nbatches] MI_NO_SIGNAL / MI_SIGNAL per batch (channel_t.axcindicate)
+ *   axc        [nstreams][nch][nbatches] MI_NO_SIGNAL / MI_SIGNAL (/ MI_AFC_UP / MI_AFC_DOWN on afc channels) per batch
+ *              (channel_t.axcindicate)
  *   stats      [nstreams][nch] or NULL
  * Synchronous: on return the outputs are complete (publish waveavail after this returns). */
 int mi_demod_process(mi_demod* h, const uint8_t* const* iq, int nbatches, float* waveout, float* iq_out, char* axc,

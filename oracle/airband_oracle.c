@@ -811,10 +811,60 @@ static void convert_window(ao_demod* d, const unsigned char* win) {
     }
 }
 
-/* the per-channel sample loop, rtl_airband.cpp:517-669 (AFC omitted: afc==0 only) */
+/* the per-channel sample loop, rtl_airband.cpp:517-669 */
+/* class AFC, rtl_airband.cpp:180-251.  square(): :186-192; check<STEP>: :193-219; finalize: :224-249. */
+static float afc_square(const float* fft_results, size_t index) {
+    return fft_results[2 * index] * fft_results[2 * index] + fft_results[2 * index + 1] * fft_results[2 * index + 1];
+}
+
+size_t ao_afc_check(const float* fft_results, size_t fft_size, int step, size_t base, float base_value, unsigned char afc) {
+    float threshold = 0;
+    size_t bin;
+    for (bin = base;; bin += (size_t)step) {
+        if (step < 0) {
+            if (bin < (size_t)-step)
+                break;
+        } else if ((size_t)(bin + (size_t)step) >= fft_size)
+            break;
+        const float value = afc_square(fft_results, (size_t)(bin + (size_t)step));
+        if (value <= base_value)
+            break;
+        if (base == bin) {
+            threshold = (value - base_value) / (float)afc;
+        } else {
+            if ((value - base_value) < threshold)
+                break;
+            threshold += threshold / 10.0; /* double arithmetic, stored back to float */
+        }
+    }
+    return bin;
+}
+
+static void afc_finalize(ao_demod* d, ao_channel* channel, char prev_axcindicate) {
+    if (channel->afc == 0)
+        return;
+    const char axcindicate = channel->axcindicate;
+    if (axcindicate != ' ' && prev_axcindicate == ' ') {
+        const size_t base = channel->base_bin;
+        const float base_value = afc_square(d->fftout, base);
+        size_t bin = ao_afc_check(d->fftout, d->fft_size, -1, base, base_value, channel->afc);
+        if (bin == base)
+            bin = ao_afc_check(d->fftout, d->fft_size, 1, base, base_value, channel->afc);
+        if (channel->bin != bin) {
+            channel->bin = bin;
+            if (bin > base)
+                channel->axcindicate = '<'; /* AFC_UP, boondock_airband.h:101 */
+            else if (bin < base)
+                channel->axcindicate = '>'; /* AFC_DOWN */
+        }
+    } else if (axcindicate == ' ' && prev_axcindicate != ' ')
+        channel->bin = channel->base_bin;
+}
+
 static void channel_batch(ao_demod* d, int ci) {
     ao_channel* channel = &d->ch[ci];
     ao_squelch* sq = &channel->squelch;
+    const char prev_axcindicate = channel->axcindicate; /* AFC afc(dev, i), rtl_airband.cpp:518 */
     channel->axcindicate = ' ';
     for (int j = AO_AGC_EXTRA; j < AO_WAVE_BATCH + AO_AGC_EXTRA; j++) {
         float* real = &channel->iq_in[2 * (j - AO_AGC_EXTRA)];
@@ -908,6 +958,7 @@ static void channel_batch(ao_demod* d, int ci) {
     memmove(channel->wavein, channel->wavein + AO_WAVE_BATCH, (size_t)(d->waveend - AO_WAVE_BATCH) * sizeof(float));
     if (channel->needs_raw_iq)
         memmove(channel->iq_in, channel->iq_in + 2 * AO_WAVE_BATCH, (size_t)(d->waveend - AO_WAVE_BATCH) * sizeof(float) * 2);
+    afc_finalize(d, channel, prev_axcindicate); /* rtl_airband.cpp:648-652 */
     if (channel->axcindicate != ' ')
         channel->active_counter++;
 }

@@ -241,6 +241,10 @@ void ao_demod_output_carry(ao_demod* d);
 int ao_demod_run(ao_demod* d, const unsigned char* iq, size_t nbytes, int max_batches, float* waveout, float* iq_out,
                  char* axc);
 
+/* AFC::check<STEP> (rtl_airband.cpp:193-219): walk from `base` in direction step (-1 / +1) over the squared magnitudes of
+ * the interleaved spectrum while they keep rising fast enough; returns the bin reached. */
+size_t ao_afc_check(const float* fft_results, size_t fft_size, int step, size_t base, float base_value, unsigned char afc);
+
 /* Stage-1 only (convert x window -> FFT -> bins): mag[ch][nfft], iq[ch][2*nfft] (iq may be NULL). */
 void ao_stage1(ao_demod* d, const unsigned char* iq, size_t nfft, float* mag, float* iqout);
 

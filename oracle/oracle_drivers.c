@@ -211,3 +211,11 @@ void ao_squelch_core_trace(const ao_squelch_cfg* cfg, const float* raw, size_t n
             ao_squelch_process_raw(&sq, raw[i]);
     }
 }
+
+/* dev->bins[] as AFC left them (rtl_airband.cpp:224-249) */
+void ao_demod_bins(const ao_demod* d, int32_t* bins, int32_t* base_bins) {
+    for (int i = 0; i < d->nch; i++) {
+        bins[i] = (int32_t)d->ch[i].bin;
+        base_bins[i] = (int32_t)d->ch[i].base_bin;
+    }
+}

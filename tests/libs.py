@@ -156,6 +156,10 @@ def oracle_lib():
         lib.ao_demod_run.restype = C.c_int
         lib.ao_stage1.argtypes = [C.c_void_p, u8p, C.c_size_t, f32p, C.c_void_p]
         lib.ao_stage1.restype = None
+        lib.ao_afc_check.argtypes = [f32p, C.c_size_t, C.c_int, C.c_size_t, C.c_float, C.c_ubyte]
+        lib.ao_afc_check.restype = C.c_size_t
+        lib.ao_demod_bins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ao_demod_bins.restype = None
         lib.ao_window.argtypes = [f32p, C.c_size_t]
         lib.ao_window.restype = None
         lib.ao_bin_for_freq.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t]
@@ -220,6 +224,12 @@ class OracleDemod:
         iqo = np.zeros((self.nch, nfft, 2), np.float32) if want_iq else None
         self.lib.ao_stage1(self.h, iq, nfft, mag, None if iqo is None else iqo.ctypes.data_as(C.c_void_p))
         return mag, iqo
+
+    def bins(self):
+        """(dev->bins, dev->base_bins) as AFC left them."""
+        cur, base = np.zeros(self.nch, np.int32), np.zeros(self.nch, np.int32)
+        self.lib.ao_demod_bins(self.h, cur.ctypes.data_as(C.c_void_p), base.ctypes.data_as(C.c_void_p))
+        return cur, base
 
     def close(self):
         if self.h:

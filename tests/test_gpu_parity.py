@@ -196,10 +196,10 @@ def test_error_paths(pkg):
         pkg.Demod(pkg.device_cfg(fft_size_log=7), chans)
     assert e.value.code == pkg.MI_ERR_INVALID
     bad = list(chans)
-    bad[0] = pkg.channel_cfg(chans[0].freq, afc=2)
+    bad[0] = pkg.channel_cfg(chans[0].freq, afc=256)  # unsigned char in the reference (config.cpp:355)
     with pytest.raises(pkg.MiError) as e:
         pkg.Demod(dev, bad)
-    assert e.value.code == pkg.MI_ERR_UNSUPPORTED
+    assert e.value.code == pkg.MI_ERR_INVALID
     d = pkg.Demod(dev, chans, max_batches=2)
     with pytest.raises(pkg.MiError):
         d.process([np.zeros(d.bytes_needed(3), np.uint8)], 3)  # more than max_batches
@@ -333,3 +333,47 @@ def test_time_parallel_core_chain_exact_and_no_fallback(pkg, monkeypatch):
             assert diag[2] == 0, f"ch{c}: serial fallback engaged, scans={diag.tolist()}"
             assert diag[0] <= nbat // 8 + 2, f"ch{c}: unexpectedly many segments re-run: {diag.tolist()}"
     d.close()
+
+
+# ---- AFC (rtl_airband.cpp:180-251): the picked bin follows an off-centre carrier, batch by batch ----
+def afc_case(pkg, nbat, fft_size_log=9):
+    centre = 120_000_000
+    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=fft_size_log)
+    binw = dev.sample_rate // (1 << fft_size_log)
+    freqs = [centre - 900_000 + 300_000 * k for k in range(6)]
+    afcs = [1, 2, 0, 5, 255, 1]
+    deltas = [2 * binw, -2 * binw, 2 * binw, 3 * binw, -binw, 0]
+    mods = [pkg.MOD_AM, pkg.MOD_AM, pkg.MOD_AM, pkg.MOD_AM, pkg.MOD_NFM, pkg.MOD_AM]
+    chans = [pkg.channel_cfg(f, modulation=m, afc=a) for f, m, a in zip(freqs, mods, afcs)]
+    carriers = [(f - centre + d, 0 if m == pkg.MOD_AM else 1, 3072, 0) for f, d, m in zip(freqs, deltas, mods)]
+    cfg = pkg.iqgen_cfg(sample_rate=dev.sample_rate, gate_samples=dev.sample_rate // 4, carriers=carriers)
+    iq = pkg.iqgen_host(cfg, 0, 0, bytes_for_batches(dev, nbat) // 2)
+    return dev, chans, iq
+
+
+@pytest.mark.parametrize("per_call", [1, 5, 16])
+def test_afc_follows_the_carrier_like_the_oracle(pkg, per_call):
+    dev, chans, iq = afc_case(pkg, 16)
+    wo, axc, st = check_against_oracle(pkg, dev, chans, iq, 16, per_call=per_call)
+    seen = [{chr(x) for x in axc[0, c]} for c in range(len(chans))]
+    assert "<" in seen[0] and ">" in seen[1]          # AFC_UP / AFC_DOWN were reported
+    assert seen[2] <= {" ", "*"}                       # afc = 0 never reports a move
+
+
+def test_afc_other_fft_size_and_checkpoint(pkg):
+    dev, chans, iq = afc_case(pkg, 12, fft_size_log=10)
+    nb, owo, oaxc, _ = oracle_run(dev, chans, iq, 12)
+    a = pkg.Demod(dev, chans, max_batches=6)
+    wo1, axc1, _, _ = a.process([iq], 6)
+    blob = a.get_state()  # carries the moved bins and the previous indicator (ChanState)
+    a.close()
+    b = pkg.Demod(dev, chans, max_batches=6)
+    b.set_state(blob)
+    pos = (6 * WAVE_BATCH + AGC_EXTRA) * b.hop_bytes
+    wo2, axc2, _, _ = b.process([iq[pos:]], 6)
+    b.close()
+    wo = np.concatenate([wo1[0, :, :6 * WAVE_BATCH], wo2[0, :, :6 * WAVE_BATCH]], axis=1)
+    axc = np.concatenate([axc1[0], axc2[0]], axis=1)
+    assert_same(axc, oaxc, "axcindicate per batch")
+    assert_same(wo, owo, "audio")
+    assert any(chr(x) in "<>" for x in axc.reshape(-1))

@@ -99,8 +99,9 @@ def test_plan_rejects_what_the_reference_rejects(pkg):
             pkg.Plan(ok, [bad])
         assert e.value.code == pkg.MI_ERR_INVALID
     with pytest.raises(pkg.MiError) as e:
-        pkg.Plan(ok, [pkg.channel_cfg(centre, afc=1)])
-    assert e.value.code == pkg.MI_ERR_UNSUPPORTED
+        pkg.Plan(ok, [pkg.channel_cfg(centre, afc=300)])
+    assert e.value.code == pkg.MI_ERR_INVALID
+    pkg.Plan(ok, [pkg.channel_cfg(centre, afc=255)]).close()
     with pytest.raises(pkg.MiError):
         pkg.Plan(ok, [])
 
