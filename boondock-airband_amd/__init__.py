@@ -76,12 +76,16 @@ class IqGenCfg(C.Structure):
 
 
 # every symbol include/mi_airband.h declares
+class MixInput(C.Structure):  # mi_mix_input
+    _fields_ = [("row", C.c_int), ("ampfactor", C.c_float), ("balance", C.c_float)]
+
+
 ABI_SYMBOLS = [
     "mi_last_error", "mi_device_count", "mi_demod_create", "mi_demod_destroy", "mi_demod_bytes_needed", "mi_demod_bytes_consumed",
     "mi_demod_hop_bytes", "mi_demod_process", "mi_demod_process_device", "mi_demod_get_stats", "mi_demod_state_size",
     "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_tp_debug", "mi_demod_kernel_time","mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
     "mi_plan_window", "mi_plan_twiddles", "mi_plan_levels", "mi_plan_sincos_lut", "mi_plan_channel", "mi_plan_ctcss_coeffs",
-    "mi_iqgen_host", "mi_iqgen_device",
+    "mi_iqgen_host", "mi_iqgen_device", "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_is_stereo", "mi_mixer_process_device",
 ]
 
 _lib = None
@@ -117,6 +121,11 @@ def lib():
         L.mi_demod_tp_debug.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_int)]
         L.mi_demod_read_planes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.mi_demod_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.mi_mixer_create.argtypes = [C.POINTER(MixInput), C.c_int, C.c_int, C.POINTER(vp)]
+        L.mi_mixer_destroy.argtypes = [vp]
+        L.mi_mixer_destroy.restype = None
+        L.mi_mixer_is_stereo.argtypes = [vp]
+        L.mi_mixer_process_device.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp, vp, vp, vp]
         L.mi_plan_create.argtypes = [C.POINTER(DeviceCfg), C.POINTER(ChannelCfg), C.c_int, C.POINTER(vp)]
         L.mi_plan_destroy.argtypes = [vp]
         L.mi_plan_destroy.restype = None
@@ -338,6 +347,30 @@ def iqgen_host(cfg, stream_id, first, count):
 
 def iqgen_device(cfg, first_stream_id, nstreams, stream_stride, first, count, d_out_ptr, hip_stream=None):
     _check(lib().mi_iqgen_device(C.byref(cfg), first_stream_id, nstreams, stream_stride, first, count, d_out_ptr, hip_stream))
+
+
+class Mixer:
+    """One mixer_t (src/mixer.cpp) over device-resident audio: inputs = [(row, ampfactor, balance), ...]."""
+
+    def __init__(self, inputs, gpu=0):
+        arr = (MixInput * len(inputs))(*[MixInput(int(r), float(a), float(b)) for r, a, b in inputs])
+        self._h = C.c_void_p()
+        _check(lib().mi_mixer_create(arr, len(inputs), gpu, C.byref(self._h)))
+        self.stereo = bool(lib().mi_mixer_is_stereo(self._h))
+
+    def process_device(self, d_waveout, row_stride, d_axc, axc_stride, nbatches, d_left, d_right, d_axc_out, hip_stream=None):
+        _check(lib().mi_mixer_process_device(self._h, d_waveout, row_stride, d_axc, axc_stride, nbatches, d_left, d_right, d_axc_out, hip_stream))
+
+    def close(self):
+        if self._h:
+            lib().mi_mixer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- the BASELINE.json channel plans (SURVEY 8d) ----

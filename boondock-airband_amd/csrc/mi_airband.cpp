@@ -20,6 +20,16 @@ namespace {
 
 thread_local std::string g_err;
 
+}  // namespace
+
+namespace mi {
+std::string& last_error_ref() {  // shared with mixer.hip
+    return g_err;
+}
+}  // namespace mi
+
+namespace {
+
 int fail(int code, const std::string& what) {
     g_err = what;
     return code;

@@ -218,6 +218,31 @@ int mi_iqgen_host(const mi_iqgen_cfg* cfg, uint32_t stream_id, uint64_t first, u
 int mi_iqgen_device(const mi_iqgen_cfg* cfg, uint32_t first_stream_id, uint32_t nstreams, size_t stream_stride_bytes, uint64_t first,
                     uint64_t count, void* d_out, void* hip_stream);
 
+/* ---------------- mixer (src/mixer.cpp:56-98 connect, :114-140 put/mix, :157-261 thread) ----------------
+ * One mixer_t: per WAVE_BATCH the output is zeroed, then every input that had a signal in that batch
+ * (channel->axcindicate != NO_SIGNAL, output.cpp:564) is added as `sum[s] += in[s] * (ampfactor * ampl)` -- and
+ * `* (ampfactor * ampr)` into the right channel when the mixer is stereo (some input has balance != 0,
+ * mixer.cpp:82-83) -- in input order; an input whose multiplier is 0.0f is skipped (mixer.cpp:133-136); the mixer's
+ * axcindicate is SIGNAL iff some input had one.  The reference mixes inputs in arrival order under jitter; this is the
+ * jitter-free order (input index).  Inputs are rows of the audio the demod entry points write
+ * ([row][row_stride] floats with row = stream * nch + channel, flags [row][axc_stride]), so on a multi-GPU job the
+ * mixer runs on rank 0 over the gathered audio. */
+typedef struct {
+    int row;         /* stream * nch + channel of the audio buffer handed to mi_mixer_process_device */
+    float ampfactor; /* mixer output's `ampfactor` (config.cpp:181), default 1 */
+    float balance;   /* -1 .. 1 (config.cpp:182-186), default 0 */
+} mi_mix_input;
+typedef struct mi_mixer mi_mixer;
+
+int mi_mixer_create(const mi_mix_input* inputs, int ninputs, int gpu, mi_mixer** out);
+void mi_mixer_destroy(mi_mixer* m);
+int mi_mixer_is_stereo(const mi_mixer* m);
+/* d_waveout/d_axc: device buffers as written by mi_demod_process_device (nbatches batches); d_left / d_right:
+ * [nbatches * WAVE_BATCH] (d_right may be NULL for a mono mixer, must not be for a stereo one); d_axc_out: [nbatches].
+ * Enqueued on `hip_stream`, asynchronous. */
+int mi_mixer_process_device(mi_mixer* m, const float* d_waveout, size_t row_stride, const char* d_axc, size_t axc_stride, int nbatches,
+                            float* d_left, float* d_right, char* d_axc_out, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1028,3 +1028,39 @@ void ao_stage1(ao_demod* d, const unsigned char* iq, size_t nfft, float* mag, fl
         }
     }
 }
+
+/* ---- mixer (src/mixer.cpp): mixer_connect_input :56-98, mix_waveforms :133-140, mixer_thread :190-213 ---- */
+void ao_mix_waveforms(float* sum, const float* in, float mult, int size) { /* mixer.cpp:133-140 */
+    if (mult == 0.0f)
+        return;
+    for (int s = 0; s < size; s++)
+        sum[s] += in[s] * mult;
+}
+
+int ao_mixer_run(const ao_mix_input* inputs, int ninputs, const float* waveout, size_t row_stride, const char* axc, size_t axc_stride,
+                 int nbatches, float* left, float* right, char* axc_out) {
+    int stereo = 0;
+    for (int j = 0; j < ninputs; j++)
+        if (inputs[j].balance != 0.0f)
+            stereo = 1; /* mixer.cpp:82-83 */
+    for (int b = 0; b < nbatches; b++) {
+        float* l = left + (size_t)b * AO_WAVE_BATCH;
+        float* r = right ? right + (size_t)b * AO_WAVE_BATCH : NULL;
+        memset(l, 0, AO_WAVE_BATCH * sizeof(float)); /* mixer.cpp:194-199 */
+        if (stereo && r)
+            memset(r, 0, AO_WAVE_BATCH * sizeof(float));
+        axc_out[b] = ' ';
+        for (int j = 0; j < ninputs; j++) { /* inputs in index order: the jitter-free order of mixer.cpp:190-213 */
+            const ao_mix_input* in = &inputs[j];
+            const float ampl = fminf(1.0f, 1.0f - in->balance), ampr = fminf(1.0f, 1.0f + in->balance); /* mixer.cpp:80-81 */
+            if (axc[(size_t)in->row * axc_stride + (size_t)b] == ' ') /* has_signal, output.cpp:564 */
+                continue;
+            const float* src = waveout + (size_t)in->row * row_stride + (size_t)b * AO_WAVE_BATCH;
+            ao_mix_waveforms(l, src, in->ampfactor * ampl, AO_WAVE_BATCH);
+            if (stereo && r)
+                ao_mix_waveforms(r, src, in->ampfactor * ampr, AO_WAVE_BATCH);
+            axc_out[b] = '*';
+        }
+    }
+    return stereo;
+}

@@ -248,6 +248,17 @@ size_t ao_afc_check(const float* fft_results, size_t fft_size, int step, size_t 
 /* Stage-1 only (convert x window -> FFT -> bins): mag[ch][nfft], iq[ch][2*nfft] (iq may be NULL). */
 void ao_stage1(ao_demod* d, const unsigned char* iq, size_t nfft, float* mag, float* iqout);
 
+/* ---- mixer (src/mixer.cpp) ---- */
+typedef struct {
+    int row; /* row of the audio buffer: stream * nch + channel */
+    float ampfactor, balance;
+} ao_mix_input;
+void ao_mix_waveforms(float* sum, const float* in, float mult, int size);
+/* One mixer over `nbatches` batches of audio [row][row_stride] with per-batch indicators [row][axc_stride]; inputs are
+ * mixed in index order.  left/right: [nbatches*WAVE_BATCH] (right may be NULL for a mono mixer); returns 1 if stereo. */
+int ao_mixer_run(const ao_mix_input* inputs, int ninputs, const float* waveout, size_t row_stride, const char* axc, size_t axc_stride,
+                 int nbatches, float* left, float* right, char* axc_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,6 +156,8 @@ def oracle_lib():
         lib.ao_demod_run.restype = C.c_int
         lib.ao_stage1.argtypes = [C.c_void_p, u8p, C.c_size_t, f32p, C.c_void_p]
         lib.ao_stage1.restype = None
+        lib.ao_mixer_run.argtypes = [C.c_void_p, C.c_int, f32p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, f32p, C.c_void_p, C.c_void_p]
+        lib.ao_mixer_run.restype = C.c_int
         lib.ao_afc_check.argtypes = [f32p, C.c_size_t, C.c_int, C.c_size_t, C.c_float, C.c_ubyte]
         lib.ao_afc_check.restype = C.c_size_t
         lib.ao_demod_bins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -238,3 +240,21 @@ class OracleDemod:
 
     def __del__(self):
         self.close()
+
+
+class MixInput(C.Structure):  # ao_mix_input
+    _fields_ = [("row", C.c_int), ("ampfactor", C.c_float), ("balance", C.c_float)]
+
+
+def oracle_mixer(inputs, waveout, axc, nbatches):
+    """ao_mixer_run over audio [rows][>= nbatches*WAVE_BATCH] and flags [rows][nbatches]: (left, right or None, axc_out)."""
+    lib = oracle_lib()
+    arr = (MixInput * len(inputs))(*[MixInput(int(r), float(a), float(b)) for r, a, b in inputs])
+    waveout = np.ascontiguousarray(waveout, np.float32)
+    axc = np.ascontiguousarray(axc, np.uint8)
+    left = np.full(nbatches * WAVE_BATCH, np.nan, np.float32)
+    right = np.full(nbatches * WAVE_BATCH, np.nan, np.float32)
+    out = np.zeros(nbatches, np.uint8)
+    stereo = lib.ao_mixer_run(arr, len(inputs), waveout.reshape(-1), waveout.shape[1], axc.ctypes.data_as(C.c_void_p), axc.shape[1], nbatches, left,
+                              right.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return left, (right if stereo else None), out

@@ -377,3 +377,44 @@ def test_afc_other_fft_size_and_checkpoint(pkg):
     assert_same(axc, oaxc, "axcindicate per batch")
     assert_same(wo, owo, "audio")
     assert any(chr(x) in "<>" for x in axc.reshape(-1))
+
+
+# ---- mixer on the device (src/mixer.cpp), fed by the audio the demod entry left in HBM ----
+@pytest.mark.parametrize("stereo", [False, True])
+def test_mixer_on_device_equals_oracle(pkg, stereo):
+    import torch
+    import libs
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    nbat, nstreams = 8, 2
+    iq0, cfg = gen_iq(pkg, dev, centre, chans, nbat)
+    nbytes = (iq0.size + 255) // 256 * 256
+    d_iq = torch.zeros((nstreams, nbytes), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    pkg.iqgen_device(cfg, 0, nstreams, nbytes, 0, iq0.size // 2, d_iq.data_ptr(), s)  # stream ids 0, 1: different noise
+    d = pkg.Demod(dev, chans, nstreams=nstreams, max_batches=nbat)
+    rows = nstreams * len(chans)
+    d_wo = torch.zeros((rows, nbat * WAVE_BATCH), dtype=torch.float32, device="cuda")
+    d_axc = torch.zeros((rows, nbat), dtype=torch.uint8, device="cuda")
+    d.process_device(d_iq.data_ptr(), nbytes, nbat, d_wo.data_ptr(), d_axc.data_ptr(), hip_stream=s)
+    bal = (lambda k: [-1.0, 1.0, 0.25, 0.0][k % 4]) if stereo else (lambda k: 0.0)
+    inputs = [(r, [1.0, 0.5, 2.0, 0.0][k % 4], bal(k)) for k, r in enumerate([0, 9, 2, 4, 8, 10, 3, 14])]
+    m = pkg.Mixer(inputs)
+    assert m.stereo == stereo
+    d_l = torch.full((nbat * WAVE_BATCH,), float("nan"), dtype=torch.float32, device="cuda")
+    d_r = torch.full((nbat * WAVE_BATCH,), float("nan"), dtype=torch.float32, device="cuda")
+    d_out = torch.zeros(nbat, dtype=torch.uint8, device="cuda")
+    m.process_device(d_wo.data_ptr(), nbat * WAVE_BATCH, d_axc.data_ptr(), nbat, nbat, d_l.data_ptr(), d_r.data_ptr() if stereo else None,
+                     d_out.data_ptr(), hip_stream=s)
+    torch.cuda.synchronize()
+    wo, axc = d_wo.cpu().numpy(), d_axc.cpu().numpy()
+    assert (axc == ord("*")).any() and (axc == ord(" ")).any()
+    el, er, eout = libs.oracle_mixer(inputs, wo, axc, nbat)
+    assert_same(d_l.cpu().numpy(), el, "mixer left")
+    assert_same(d_out.cpu().numpy(), eout, "mixer axcindicate")
+    if stereo:
+        assert_same(d_r.cpu().numpy(), er, "mixer right")
+    m.close()
+    d.close()
+    with pytest.raises(pkg.MiError):
+        pkg.Mixer([(0, 1.0, 1.5)])  # balance out of range (config.cpp:183-186)
