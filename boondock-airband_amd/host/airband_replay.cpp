@@ -5,6 +5,10 @@
 // Deterministic drive: the feeder hands over less than one batch at a time and waits until the demod
 // thread has starved and the output side has drained, so no batch is ever overrun and EOF drops nothing.
 //
+// Besides the raw audio it writes what the reference's outputs would carry for the same capture (output_adapters.hpp):
+// <prefix>_ch<i>.cf32 = the O_RAWFILE byte stream of a non-continuous rawfile output (channels with has_iq_outputs),
+// <prefix>_ch<i>.udp  = the concatenated datagram payloads of a non-continuous mono udp_stream output.
+//
 // usage: airband_replay <config.txt> <capture.iq> <out_prefix> [gpu]
 //   config.txt: line 1 "sample_rate centerfreq fft_size_log sfmt tau fm_quadri"
 //               then per channel "freq modulation squelch_threshold_dbfs has_snr snr_db notch notch_q ctcss bandwidth ampfactor tau afc has_iq"
@@ -17,17 +21,28 @@
 #include <vector>
 
 #include "airband_host.hpp"
+#include "output_adapters.hpp"
 
 struct Sink {
     std::vector<FILE*> audio;
+    std::vector<rawfile_out_t> raw;  // f == nullptr for channels without a rawfile output
+    std::vector<FILE*> udp;
     std::vector<std::string> flags;
     size_t batches = 0;
 };
 
-static void sink_fn(void* user, int /*device*/, int channel, const float* waveout, const float* /*iq_out*/, char axc) {
+static void sink_fn(void* user, int /*device*/, int channel, const float* waveout, const float* iq_out, char axc) {
     Sink* s = (Sink*)user;
-    fwrite(waveout, sizeof(float), WAVE_BATCH, s->audio[(size_t)channel]);
-    s->flags[(size_t)channel].push_back(axc);
+    const size_t c = (size_t)channel;
+    fwrite(waveout, sizeof(float), WAVE_BATCH, s->audio[c]);
+    s->flags[c].push_back(axc);
+    if (s->raw[c].f && iq_out)
+        rawfile_put(&s->raw[c], iq_out, axc);
+    if (udp_stream_sends(false, axc)) {
+        static thread_local std::vector<unsigned char> payload(udp_payload_bytes(false));
+        const size_t n = udp_payload_mono(waveout, payload.data());
+        fwrite(payload.data(), 1, n, s->udp[c]);
+    }
 }
 
 int main(int argc, char** argv) {
@@ -79,6 +94,11 @@ int main(int argc, char** argv) {
         std::string p = std::string(argv[3]) + "_ch" + std::to_string(i) + ".f32";
         sink.audio.push_back(fopen(p.c_str(), "wb"));
         sink.flags.emplace_back();
+        rawfile_out_t rf;
+        if (chans[i].has_iq_outputs)
+            rf.f = fopen((std::string(argv[3]) + "_ch" + std::to_string(i) + ".cf32").c_str(), "wb");
+        sink.raw.push_back(rf);
+        sink.udp.push_back(fopen((std::string(argv[3]) + "_ch" + std::to_string(i) + ".udp").c_str(), "wb"));
     }
     FILE* iq = fopen(argv[2], "rb");
     if (!iq) {
@@ -121,6 +141,11 @@ int main(int argc, char** argv) {
     pthread_join(th, NULL);
     fclose(iq);
     for (FILE* f : sink.audio)
+        fclose(f);
+    for (rawfile_out_t& r : sink.raw)
+        if (r.f)
+            fclose(r.f);
+    for (FILE* f : sink.udp)
         fclose(f);
     std::string fp = std::string(argv[3]) + "_axc.txt";
     FILE* ff = fopen(fp.c_str(), "w");

@@ -65,3 +65,17 @@ def test_replay_through_ring_equals_oracle(pkg, tmp_path, case):
         got = np.fromfile(tmp_path / f"out_ch{c}.f32", dtype=np.float32)
         assert_same(got, owo[c], f"{case} ch{c} audio through the ring")
         assert flags[c] == bytes(oaxc[c]).decode(), f"{case} ch{c} axcindicate"
+    # the byte streams of the reference's rawfile / udp_stream outputs for this capture (host/output_adapters.hpp)
+    nb, owo, oaxc, oiq = oracle_run(dev, chans, iq, nbat, want_iq=True)
+    for c, ch in enumerate(chans):
+        sig = oaxc[c] != ord(" ")
+        udp = np.fromfile(tmp_path / f"out_ch{c}.udp", dtype=np.float32)
+        want = np.concatenate([owo[c, b * WAVE_BATCH:(b + 1) * WAVE_BATCH] for b in range(nbat) if sig[b]] or [np.zeros(0, np.float32)])
+        assert_same(udp, want, f"{case} ch{c} udp_stream payloads (non-continuous: signal batches only)")
+        if ch.has_iq_outputs:
+            # non-continuous rawfile: signal batches plus the one trailing batch after each transmission (output.cpp:516-519,560)
+            keep = [b for b in range(nbat) if sig[b] or (b > 0 and sig[b - 1])]
+            raw = np.fromfile(tmp_path / f"out_ch{c}.cf32", dtype=np.float32)
+            want = np.concatenate([oiq[c, 2 * b * WAVE_BATCH:2 * (b + 1) * WAVE_BATCH] for b in keep] or [np.zeros(0, np.float32)])
+            assert_same(raw, want, f"{case} ch{c} rawfile cf32 stream")
+            assert raw.size > 0
