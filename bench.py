@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--noise-only", action="store_true", help="diagnostic: no carriers in the synthetic capture (squelch never opens)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of audio to rank 0 (N>1)")
     ap.add_argument("--diag", action="store_true", help="print the time-parallel path's per-channel counters to stderr")
+    ap.add_argument("--workload", choices=["config2", "config3", "config4"], default="config2",
+                    help="config2 = BASELINE configs[1], the bench line (default); config3 = 1 stream x 32 mixed AM/NFM/CTCSS channels at fft 2048; "
+                         "config4 = 64 streams x the config-3 plan at fft 512 (extra measurements, not the driver's line)")
     args = ap.parse_args()
 
     import torch
@@ -90,26 +93,35 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    centre, chans = pkg.config2_channels()
-    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=9)
+    nstreams, fft_log = 1, 9
+    if args.workload == "config2":
+        centre, chans = pkg.config2_channels()
+    else:
+        centre, chans = pkg.config3_channels()
+        nstreams, fft_log = (1, 11) if args.workload == "config3" else (64, 9)
+        if args.seconds == 64.0:
+            args.seconds = 8.0 if args.workload == "config3" else 2.0
+        args.cpu_seconds = 0.0
+    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=fft_log)
     nch = len(chans)
     nbat = max(1, int(round(args.seconds * 8)))
     nsteps = nbat * WAVE_BATCH
     hop = 2 * (SAMPLE_RATE // 16000)
-    nbytes = ((nsteps + AGC_EXTRA) * hop + 2 * 512 + 255) // 256 * 256
+    nbytes = ((nsteps + AGC_EXTRA) * hop + 2 * (1 << fft_log) + 255) // 256 * 256
     stream = torch.cuda.current_stream()
 
     # synthetic capture of this rank's stream, generated on the device (same integer recipe as the host generator)
-    gcfg = pkg.iqgen_cfg(sample_rate=SAMPLE_RATE, gate_samples=SAMPLE_RATE, carriers=() if args.noise_only else pkg.carriers_for(centre, chans))
-    d_iq = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    pkg.iqgen_device(gcfg, rank, 1, nbytes, 0, nbytes // 2, d_iq.data_ptr(), stream.cuda_stream)
-    d_wo = torch.empty((1, nch, nsteps), dtype=torch.float32, device="cuda")
-    d_axc = torch.empty((1, nch, nbat), dtype=torch.uint8, device="cuda")
+    amp = {} if args.workload == "config2" else {"amp_q8": 1024}  # 16 carriers: keep the sum inside the u8 range
+    gcfg = pkg.iqgen_cfg(sample_rate=SAMPLE_RATE, gate_samples=SAMPLE_RATE, carriers=() if args.noise_only else pkg.carriers_for(centre, chans, **amp))
+    d_iq = torch.empty((nstreams, nbytes), dtype=torch.uint8, device="cuda")
+    pkg.iqgen_device(gcfg, rank * nstreams, nstreams, nbytes, 0, nbytes // 2, d_iq.data_ptr(), stream.cuda_stream)
+    d_wo = torch.empty((nstreams, nch, nsteps), dtype=torch.float32, device="cuda")
+    d_axc = torch.empty((nstreams, nch, nbat), dtype=torch.uint8, device="cuda")
     gather_list = None
     if world > 1 and not args.no_gather and rank == 0:
         gather_list = [torch.empty_like(d_wo) for _ in range(world)]
 
-    h = pkg.Demod(dev, chans, nstreams=1, max_batches=nbat, gpu=local_rank)
+    h = pkg.Demod(dev, chans, nstreams=nstreams, max_batches=nbat, gpu=local_rank)
     # prime: the handle's first call consumes AGC_EXTRA extra windows (waveend starts at 0 in the reference)
     h.process_device(d_iq.data_ptr(), nbytes, nbat, d_wo.data_ptr(), d_axc.data_ptr(), hip_stream=stream.cuda_stream)
     base = d_iq.data_ptr() + AGC_EXTRA * hop
@@ -144,7 +156,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    samples_per_step_per_gpu = nsteps * (SAMPLE_RATE // 16000)
+    samples_per_step_per_gpu = nsteps * (SAMPLE_RATE // 16000) * nstreams
     total_samples = samples_per_step_per_gpu * args.steps * world
     value = total_samples / dt / 1e6  # MS/s, whole job
 
@@ -177,7 +189,7 @@ def main():
         # only quoted when the launch geometry is the one that was profiled (default --seconds, default chunking).
         traffic, traffic_src = {}, None
         pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
-        if os.path.exists(pmc) and nbat == 512 and not args.noise_only and "MI_AIRBAND_TP_CHUNKS" not in os.environ:
+        if os.path.exists(pmc) and nbat == 512 and args.workload == "config2" and not args.noise_only and "MI_AIRBAND_TP_CHUNKS" not in os.environ:
             import csv
             for row in csv.DictReader(open(pmc)):
                 traffic[row["kernel"]] = int(row["hbm_bytes_per_launch"])
@@ -185,7 +197,7 @@ def main():
         for name, k in kernels.items():
             k["traffic"] = traffic.get(name.split("#")[0])
         out = {
-            "metric": "IQ MS/s processed (x real-time) @ 8ch fft_size=512",
+            "metric": f"IQ MS/s processed (x real-time) @ {nch}ch fft_size={1 << fft_log}",
             "value": value,
             "unit": "MS/s",
             "n_gpus": world,
@@ -197,11 +209,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 1 device stream per GPU @ 2.56 MS/s u8 IQ, 8 AM channels, fft_size=512",
-                       "streams_per_gpu": 1, "channels": nch, "fft_size": 512, "capture_seconds_per_step": nbat / 8.0,
+            "config": {"workload": {"config2": "BASELINE configs[1]: 1 device stream per GPU @ 2.56 MS/s u8 IQ, 8 AM channels, fft_size=512",
+                                    "config3": "BASELINE configs[2]: 1 device stream, 32 channels mixed AM+NFM + CTCSS, fft_size=2048",
+                                    "config4": "BASELINE configs[3]: 64 device streams x 32 mixed channels per GPU, fft_size=512"}[args.workload],
+                       "streams_per_gpu": nstreams, "channels": nch, "fft_size": 1 << fft_log, "capture_seconds_per_step": nbat / 8.0,
                        "audio_gather_to_rank0": bool(world > 1 and not args.no_gather),
                        "stage2_path": "time-parallel" if h.last_path()[0] == 1 else "serial"},
-            "x_realtime_per_stream": value / world / (SAMPLE_RATE / 1e6),
+            "x_realtime_per_stream": value / world / nstreams / (SAMPLE_RATE / 1e6),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": kernels[dom]["traffic"],
                          "traffic_source": traffic_src,
