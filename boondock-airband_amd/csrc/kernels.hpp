@@ -105,7 +105,7 @@ hipError_t launch_afc(const AfcArgs& a, hipStream_t s);
 constexpr uint32_t TP_L = 512;      // steps per segment
 constexpr uint32_t TP_W = 4096;     // warm-up of the state machine / AGC before a segment (multiple of TP_L)
 constexpr uint32_t TP_L1 = 512;     // steps per lane of the full_ sandwich pass
-constexpr uint32_t TP_W1 = 4096;    // its warm-up
+constexpr uint32_t TP_W1 = 3072;    // its warm-up: 0.99^3072 = 4e-14 closes the sandwich over 10^6 of dynamic range (unclosed blocks are flagged invalid)
 constexpr int TP_MAXEV = 4;         // close-edge fades per segment (they are >= 197 steps apart: at most 3)
 constexpr uint32_t TP_MAXCHAIN = 32;
 constexpr int TP_NREC = 19 + TP_MAXEV;

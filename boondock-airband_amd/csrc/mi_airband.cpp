@@ -203,11 +203,34 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         // segment / scan / fix passes of chunk i-1 run on the caller's stream.
         const uint32_t n = da.nsteps;
         const uint32_t units = n / mi::TP_CHUNK_UNIT;
-        int want = 2;  // measured best on MI355X: the wide passes take a fixed ~1.6 ms per launch, so few chunks
+        // Chunk sizes grow geometrically: a short first chunk gets the serial core chain going early (its stage 1 +
+        // aggregates are all that precedes it), later chunks are long because every wide pass has a fixed latency per
+        // launch.  MI_AIRBAND_TP_CHUNKS / MI_AIRBAND_TP_RATIO override the measured defaults.
+        int want = 3;
+        double ratio = 1.5;
         if (const char* e = std::getenv("MI_AIRBAND_TP_CHUNKS"))
             want = std::max(1, std::atoi(e));
-        const uint32_t per = units == 0 ? 0 : (units + static_cast<uint32_t>(want) - 1) / static_cast<uint32_t>(want);
-        const int C = units == 0 ? 1 : static_cast<int>((units + per - 1) / per);
+        if (const char* e = std::getenv("MI_AIRBAND_TP_RATIO"))
+            ratio = std::max(1.0, std::atof(e));
+        std::vector<uint32_t> bound{0};  // chunk i covers units [bound[i], bound[i+1])
+        if (units > 0) {
+            want = std::min<int>(want, static_cast<int>(units));
+            double total = 0.0, w = 1.0;
+            for (int i = 0; i < want; ++i, w *= ratio)
+                total += w;
+            double acc = 0.0;
+            w = 1.0;
+            for (int i = 0; i < want; ++i, w *= ratio) {
+                acc += w;
+                uint32_t b = (i == want - 1) ? units : static_cast<uint32_t>(acc / total * units + 0.5);
+                b = std::max(b, bound.back() + 1);
+                b = std::min(b, units - static_cast<uint32_t>(want - 1 - i));
+                bound.push_back(b);
+            }
+        } else {
+            bound.push_back(0);
+        }
+        const int C = static_cast<int>(bound.size()) - 1;
         if (C > mi_demod::kMaxChunks)
             return fail(MI_ERR_INVALID, "too many chunks");
         while (static_cast<int>(h->chunk_ev.size()) < C * mi_demod::kEvPerChunk) {
@@ -249,8 +272,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         h->last_nseg = ta.nseg;
         auto chunk = [&](int i) {
             mi::TpArgs c = ta;
-            c.step0 = units == 0 ? 0 : static_cast<uint32_t>(i) * per * mi::TP_CHUNK_UNIT;
-            c.step1 = (i == C - 1) ? n : (static_cast<uint32_t>(i) + 1) * per * mi::TP_CHUNK_UNIT;
+            c.step0 = bound[static_cast<size_t>(i)] * mi::TP_CHUNK_UNIT;
+            c.step1 = (i == C - 1) ? n : bound[static_cast<size_t>(i) + 1] * mi::TP_CHUNK_UNIT;
             c.seg0 = c.step0 / mi::TP_L;
             c.seg1 = (c.step1 + mi::TP_L - 1) / mi::TP_L;
             c.blk0 = c.step0 / 16;
@@ -283,7 +306,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             HIP_TRY(hipEventRecord(ev(i, 0), s));
             HIP_TRY(stage1(c));
             HIP_TRY(hipEventRecord(ev(i, 1), s));
-            HIP_TRY(mi::launch_tp_front(c, s));
+            HIP_TRY(mi::launch_tp_front(c, s));  // (on its own stream it competes with the next chunk's stage 1: measured slower)
             HIP_TRY(hipEventRecord(ev(i, 2), s));
             return MI_OK;
         };

@@ -418,3 +418,35 @@ def test_mixer_on_device_equals_oracle(pkg, stereo):
     d.close()
     with pytest.raises(pkg.MiError):
         pkg.Mixer([(0, 1.0, 1.5)])  # balance out of range (config.cpp:183-186)
+
+
+def test_bench_workload_full_size_equals_oracle(pkg, monkeypatch):
+    """BASELINE configs[1] at the size bench.py times: 64 s of capture (512 batches) in one device-resident call through the
+    time-parallel path with its default chunk pipeline, IQ generated on the device -- audio and flags bit-exact vs the
+    oracle run over the same bytes (the oracle finishes 64 s x 8 channels in a few seconds)."""
+    import torch
+    monkeypatch.delenv("MI_AIRBAND_TP", raising=False)
+    monkeypatch.delenv("MI_AIRBAND_TP_CHUNKS", raising=False)
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    nbat = 512
+    nsteps = nbat * WAVE_BATCH
+    hop = 2 * (dev.sample_rate // 16000)
+    nbytes = ((nsteps + AGC_EXTRA) * hop + 2 * 512 + 255) // 256 * 256
+    s = torch.cuda.current_stream().cuda_stream
+    cfg = pkg.iqgen_cfg(sample_rate=dev.sample_rate, gate_samples=dev.sample_rate, carriers=pkg.carriers_for(centre, chans))
+    d_iq = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    pkg.iqgen_device(cfg, 0, 1, nbytes, 0, nbytes // 2, d_iq.data_ptr(), s)
+    d_wo = torch.empty((1, len(chans), nsteps), dtype=torch.float32, device="cuda")
+    d_axc = torch.empty((1, len(chans), nbat), dtype=torch.uint8, device="cuda")
+    d = pkg.Demod(dev, chans, nstreams=1, max_batches=nbat)
+    d.process_device(d_iq.data_ptr(), nbytes, nbat, d_wo.data_ptr(), d_axc.data_ptr(), hip_stream=s)
+    torch.cuda.synchronize()
+    assert d.last_path() == (1, 0), "time-parallel path, every segment verified"
+    iq = d_iq.cpu().numpy()
+    nb, owo, oaxc, _ = oracle_run(dev, chans, iq, nbat)
+    assert nb == nbat
+    assert_same(d_axc.cpu().numpy()[0], oaxc, "axcindicate, 512 batches")
+    assert_same(d_wo.cpu().numpy()[0], owo, "audio, 512 batches")
+    assert (oaxc == ord("*")).sum() >= 4 * 200 and (oaxc[1] == ord(" ")).all()
+    d.close()
