@@ -777,7 +777,22 @@ __device__ __forceinline__ float agc_audio(TpLane& s, const ChanParams& p, const
 // 0.79 den and 0.81 den.  Returns false in that case (nothing is committed; the caller takes the general path for the block).
 template <bool kAudio>
 __device__ __forceinline__ bool agc_block(float& agc_io, const ChanParams& p, const float (&xs)[16], const float (&as)[16], const float level,
-                                          float (&wv)[16]) {
+                                          const bool all_above, float (&wv)[16]) {
+    if (!kAudio && all_above) {
+        // Warm-up, every sample above the level: only agcavgfast is needed.  If |num| < 1.18 agc at every sample the
+        // quotient |num| / (1.5 agc) stays below 0.7867 (1 + 2e-7) < 0.79, so no sample clips and the average follows the
+        // plain recurrence: 7 instructions per sample.  Anything else takes the general block below.
+        float agc = agc_io, m = -1.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            agc = agc * 0.995f + xs[j] * 0.005f;
+            m = fmaxf(m, fabsf(as[j] - agc) - agc * 1.18f);
+        }
+        if (m < 0.0f && agc > 0.0f && agc < 3.0e38f) {
+            agc_io = agc;
+            return true;
+        }
+    }
     float agc = agc_io, amb = -1.0f;
     float nums[16], dens[16], cfs[16];
 #pragma unroll
@@ -894,7 +909,7 @@ __device__ __forceinline__ void tp_block(TpLane& s, const ChanParams& p, const T
         if (ok && (steady_open || wait_closing)) {  // still open: rtl_airband.cpp:574-641
             const float as[16] = {q.a0.x, q.a0.y, q.a0.z, q.a0.w, q.a1.x, q.a1.y, q.a1.z, q.a1.w,
                                   q.a2.x, q.a2.y, q.a2.z, q.a2.w, q.a3.x, q.a3.y, q.a3.z, q.a3.w};
-            ok = agc_block<kInSeg>(agc, p, xs, as, level1, wv);
+            ok = agc_block<kInSeg>(agc, p, xs, as, level1, g.x0 > level1 && g.xm > level1, wv);
         }
         if (ok) {
             settled = true;
