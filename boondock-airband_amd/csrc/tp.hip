@@ -1377,13 +1377,20 @@ hipError_t launch_tp_seg(const TpArgs& a, hipStream_t s) {
     if (a.nrows == 0 || a.step1 <= a.step0)
         return hipSuccess;
     const int lanes = a.nrows * static_cast<int>(a.seg1 - a.seg0);
-    // Lanes of one wave sit at different points of the capture, so a wave pays for every path one of its lanes takes;
-    // MI_AIRBAND_TP_LPW spreads them over more waves (measured: no gain on MI355X, the slowest wave sets the time).
-    static const int lpw = [] {
+    // Lanes of one wave sit at different points of the capture, so a wave pays for every path one of its lanes takes
+    // (a squelch edge costs ~9 us per block for the whole wave).  There are far fewer lanes than the 1024 SIMDs x 64
+    // of the machine: spread them thin -- 4 per wave measured best at one stream x 8 channels (2 waves per SIMD) --
+    // and pack more only when the launch would exceed ~2 waves per SIMD.  MI_AIRBAND_TP_LPW overrides.
+    static const int lpw_env = [] {
         const char* e = std::getenv("MI_AIRBAND_TP_LPW");
-        const int v = e ? std::atoi(e) : 64;
-        return (v >= 1 && v <= 64) ? v : 64;
+        const int v = e ? std::atoi(e) : 0;
+        return (v >= 1 && v <= 64) ? v : 0;
     }();
+    int lpw = lpw_env;
+    if (lpw == 0) {
+        lpw = (lanes + 2047) / 2048;
+        lpw = lpw < 4 ? 4 : (lpw > 64 ? 64 : lpw);
+    }
     TP_LAUNCH(k_tp_seg, (lanes + lpw - 1) / lpw, lpw);
     return hipSuccess;
 }
