@@ -236,6 +236,9 @@ __device__ __forceinline__ void ema_trial(const float (&ys)[16], const float c, 
 }
 
 __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
+    // The chain is the critical path of a call and shares its SIMD with waves of the wide passes of other chunks: ask the
+    // issue arbiter to favour it.
+    __builtin_amdgcn_s_setprio(3);
     const int r = blockIdx.x;
     const int row = a.rows[r];
     const int lane = threadIdx.x;
