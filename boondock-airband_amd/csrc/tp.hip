@@ -235,6 +235,13 @@ __device__ __forceinline__ void ema_trial(const float (&ys)[16], const float c, 
     }
 }
 
+__device__ __forceinline__ void ema_only(const float (&ys)[16], const float c, float& cs) {
+    cs = c;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        cs = cs * 0.99f + ys[j];
+}
+
 __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
     // The chain is the critical path of a call and shares its SIMD with waves of the wide passes of other chunks: ask the
     // issue arbiter to favour it.
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
         if (g0 + 128 < nblk)
             nxt2 = core_load(a, x, bbase, g0 + 128, lane);  // two groups in flight while this one is walked
         const int nb = static_cast<int>(min(64u, nblk - g0));
-        const float fe_prev = __shfl_up(cur.fe, 1);  // full_ at the start of lane's block, valid for lane > kk
+        const float fe_prev = wave_shr1(cur.fe, 0.0f);  // full_ at the start of lane's block, valid for lane > kk
         const bool boundary = ((g0 + lane) % bps) == 0;
         bool ys_ready = false;
         float yv[16];
@@ -366,7 +373,8 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                         float fe_k = fe;
                         while (kk + 1 < nb && c != fe_k) {
                             const int k1 = kk + 1;
-                            if (!(rl(cur.fm, k1) >= 0.0f))
+                            const float fm1 = rl(cur.fm, k1);
+                            if (!(fm1 >= 0.0f))
                                 break;
                             if ((g0 + k1) % bps == 0 && lane == 0) {
                                 TpCore t;
@@ -375,10 +383,17 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                             }
                             const float nf1 = noise_floor_step(nf, c);
                             const float cap1 = cap_of(p, nf1);
-                            ema_trial(yv, c, cs_l, emax_l);
-                            cs = rl(cs_l, k1), emax = rl(emax_l, k1);
-                            if (!(emax < cap1))
-                                break;
+                            if (c <= fe_k && fm1 < cap1) {
+                                // capped_ <= full_ at the block start and both follow the same monotone recurrence while the
+                                // cap does not bind, so capped_ <= full_ <= fm1 < cap throughout: no maximum to track
+                                ema_only(yv, c, cs_l);
+                                cs = rl(cs_l, k1);
+                            } else {
+                                ema_trial(yv, c, cs_l, emax_l);
+                                cs = rl(cs_l, k1), emax = rl(emax_l, k1);
+                                if (!(emax < cap1))
+                                    break;
+                            }
                             nf = nf1, cap = cap1, c = cs, kk = k1;
                             fe_k = rl(cur.fe, k1);
                             ++n_step;
