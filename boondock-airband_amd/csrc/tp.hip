@@ -796,18 +796,36 @@ __device__ __forceinline__ float agc_audio(TpLane& s, const ChanParams& p, const
 template <bool kAudio>
 __device__ __forceinline__ bool agc_block(float& agc_io, const ChanParams& p, const float (&xs)[16], const float (&as)[16], const float level,
                                           const bool all_above, float (&wv)[16]) {
-    if (!kAudio && all_above) {
-        // Warm-up, every sample above the level: only agcavgfast is needed.  If |num| < 1.18 agc at every sample the
-        // quotient |num| / (1.5 agc) stays below 0.7867 (1 + 2e-7) < 0.79, so no sample clips and the average follows the
-        // plain recurrence: 7 instructions per sample.  Anything else takes the general block below.
+    if (all_above) {
+        // Every sample above the level.  If |num| < 1.18 agc at every sample the quotient |num| / (1.5 agc) stays below
+        // 0.7867 (1 + 2e-7) < 0.79, so no sample clips and the average follows the plain recurrence: 7 instructions per
+        // sample while warming up (only agcavgfast is needed), plus the quotient itself when the audio is emitted.
+        // Anything else takes the general block below.
         float agc = agc_io, m = -1.0f;
+        float nums[16], dens[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             agc = agc * 0.995f + xs[j] * 0.005f;
-            m = fmaxf(m, fabsf(as[j] - agc) - agc * 1.18f);
+            const float num = as[j] - agc;
+            m = fmaxf(m, fabsf(num) - agc * 1.18f);
+            if (kAudio)
+                nums[j] = num, dens[j] = agc * 1.5f;
         }
         if (m < 0.0f && agc > 0.0f && agc < 3.0e38f) {
             agc_io = agc;
+            if (kAudio) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    float wout = (nums[j] / dens[j]) * p.ampfactor;
+                    if (wout != wout)
+                        wout = 0.0f;
+                    else if (wout > 1.0f)
+                        wout = 1.0f;
+                    else if (wout < -1.0f)
+                        wout = -1.0f;
+                    wv[j] = wout;
+                }
+            }
             return true;
         }
     }
