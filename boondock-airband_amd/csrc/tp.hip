@@ -1202,6 +1202,10 @@ __device__ __forceinline__ void lane_from_tstart(TpLane& s, const int* __restric
     s.agc = __int_as_float(ts[6]);
 }
 
+// kStateOnly: walk the chain for its states alone (the cheap warm-up arithmetic, no audio): every member gets its true
+// start state in tstart[] and need[] = 2, and k_tp_redo re-runs all of them side by side.  Otherwise each member is
+// re-run in place, one after the other (the serial last resort).
+template <bool kStateOnly>
 __device__ __forceinline__ void rerun_chain(const TpArgs& a, const int r, const int row, const ChanParams& p, uint32_t k, const uint32_t max_chain,
                                             const bool stop_at_flagged, const bool to_the_end) {
     const float* __restrict__ magrow = a.mag + static_cast<size_t>(row) * a.plane_stride;
@@ -1224,11 +1228,19 @@ __device__ __forceinline__ void rerun_chain(const TpArgs& a, const int r, const 
                 return;
         }
         const uint32_t s0 = k * TP_L, s1 = min(s0 + TP_L, a.nsteps);
-        const TpFsm S = canon(s);
-        const float s_agc = s.agc;
-        seg_reset(s);
-        tp_run<true>(s, p, a, r, row, magrow, s0, s1, s0 / kWaveBatch, base + k);
-        rec_store(a, base + k, S, s_agc, s);
+        if (kStateOnly) {
+            int* __restrict__ ts = a.tstart + (base + k) * 8;
+            ts[0] = s.cur, ts[1] = s.next, ts[2] = s.delay, ts[3] = s.low, ts[4] = s.recent, ts[5] = s.closed;
+            ts[6] = __float_as_int(s.agc);
+            a.need[base + k] = 2;
+            tp_run<false>(s, p, a, r, row, magrow, s0, s1, 0, base + k);
+        } else {
+            const TpFsm S = canon(s);
+            const float s_agc = s.agc;
+            seg_reset(s);
+            tp_run<true>(s, p, a, r, row, magrow, s0, s1, s0 / kWaveBatch, base + k);
+            rec_store(a, base + k, S, s_agc, s);
+        }
     }
 }
 
@@ -1239,11 +1251,37 @@ __global__ __launch_bounds__(64) void k_tp_fix(const TpArgs a) {
         return;
     const int r = gid / nsc;
     const uint32_t k = a.seg0 + static_cast<uint32_t>(gid - r * nsc);
-    if (!a.need[static_cast<size_t>(r) * a.nseg + k])
+    if (a.need[static_cast<size_t>(r) * a.nseg + k] != 1)
         return;
     const int row = a.rows[r];
     const ChanParams p = a.cp[row % a.nch];
-    rerun_chain(a, r, row, p, k, TP_MAXCHAIN, true, false);
+    rerun_chain<true>(a, r, row, p, k, TP_MAXCHAIN, true, false);
+}
+
+// every segment a chain of k_tp_fix passed through, from its true start state, audio and record included
+__global__ __launch_bounds__(64) void k_tp_redo(const TpArgs a) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nsc = static_cast<int>(a.seg1 - a.seg0);
+    if (gid >= a.nrows * nsc)
+        return;
+    const int r = gid / nsc;
+    const uint32_t k = a.seg0 + static_cast<uint32_t>(gid - r * nsc);
+    const size_t base = static_cast<size_t>(r) * a.nseg;
+    if (a.need[base + k] != 2)
+        return;
+    const int row = a.rows[r];
+    const ChanParams p = a.cp[row % a.nch];
+    const float* __restrict__ magrow = a.mag + static_cast<size_t>(row) * a.plane_stride;
+    TpLane s;
+    seg_reset(s);
+    lane_from_tstart(s, a.tstart + (base + k) * 8);
+    load_core(s, p, a.core[static_cast<size_t>(r) * (a.nseg + 1) + k]);
+    const uint32_t s0 = k * TP_L, s1 = min(s0 + TP_L, a.nsteps);
+    const TpFsm S = canon(s);
+    const float s_agc = s.agc;
+    seg_reset(s);
+    tp_run<true>(s, p, a, r, row, magrow, s0, s1, s0 / kWaveBatch, base + k);
+    rec_store(a, base + k, S, s_agc, s);
 }
 
 // last resort: one lane per channel re-runs serially everything from the first unaccepted segment
@@ -1257,7 +1295,7 @@ __global__ __launch_bounds__(64) void k_tp_fallback(const TpArgs a) {
     const int row = a.rows[r];
     const ChanParams p = a.cp[row % a.nch];
     // tstart of first_bad was written from an accepted predecessor: it is the true state
-    rerun_chain(a, r, row, p, f.first_bad, 0xffffffffu, false, true);
+    rerun_chain<false>(a, r, row, p, f.first_bad, 0xffffffffu, false, true);
 }
 
 // =====================================================================================================
@@ -1442,6 +1480,7 @@ hipError_t launch_tp_rest(const TpArgs& a_in, hipStream_t s, hipEvent_t* marks) 
         if (round == 0)
             TP_MARK(0);
         TP_LAUNCH(k_tp_fix, (lanes + 63) / 64, 64);
+        TP_LAUNCH(k_tp_redo, (lanes + 3) / 4, 4);
         if (round == 0)
             TP_MARK(1);
     }
