@@ -450,3 +450,23 @@ def test_bench_workload_full_size_equals_oracle(pkg, monkeypatch):
     assert_same(d_wo.cpu().numpy()[0], owo, "audio, 512 batches")
     assert (oaxc == ord("*")).sum() >= 4 * 200 and (oaxc[1] == ord(" ")).all()
     d.close()
+
+
+@pytest.mark.parametrize("chunks,ratio,lpw", [(1, 1, 64), (2, 1, 16), (5, 2, 1), (3, 1.5, 4)])
+def test_time_parallel_pipeline_settings_do_not_change_a_bit(pkg, monkeypatch, chunks, ratio, lpw):
+    """Chunking of the call, chunk growth and lanes per wave are scheduling choices: 160 batches (20 s, five 4-s chunk
+    units) with squelch edges in every chunk and two consecutive calls give the oracle's audio under every setting."""
+    monkeypatch.setenv("MI_AIRBAND_TP_CHUNKS", str(chunks))
+    monkeypatch.setenv("MI_AIRBAND_TP_RATIO", str(ratio))
+    monkeypatch.setenv("MI_AIRBAND_TP_LPW", str(lpw))
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    calls = [160, 40]
+    nbat = sum(calls)
+    iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=3)
+    nb, owo, oaxc, _ = oracle_run(dev, chans, iq, nbat)
+    assert nb == nbat
+    wo, axc, st, paths = _tp_run(pkg, dev, chans, iq, calls, monkeypatch)
+    assert paths == [(1, 0), (1, 0)]
+    assert_same(axc[0], oaxc, "axcindicate")
+    assert_same(wo[0], owo, "audio")
