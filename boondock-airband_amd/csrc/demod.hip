@@ -32,7 +32,18 @@ struct Ctx {
     const float* cc_slow;
     float* cq_fast;         // q1[kMaxTones], q2[kMaxTones]
     float* cq_slow;
+    // One (stream, channel) per wave: every lane carries the same channel state and executes the same instructions (a
+    // wave instruction costs the same for 1 or 64 active lanes), and the Goertzel banks are spread over the lanes --
+    // lane d holds detector d of the fast and of the slow set (<= 52 each, ctcss.cpp:61-73).
+    bool uni;
+    int lane;
+    float gf_c, gf_q1, gf_q2;  // fast set, detector `lane`
+    float gs_c, gs_q1, gs_q2;  // slow set, detector `lane`
 };
+
+__device__ __forceinline__ float lane_read(const float v, const int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 
 __device__ __forceinline__ float std_min(float a, float b) {  // std::min(a, b): b < a ? b : a
     return (b < a) ? b : a;
@@ -88,10 +99,14 @@ __device__ __forceinline__ void set_state(Ctx& c, int update) {  // squelch.cpp:
 __device__ __forceinline__ void ctcss_reset(Ctx& c) {  // CTCSS::reset on both detectors, ctcss.cpp:165-172
     if (!c.p.ctcss_enabled)
         return;
-    for (int d = 0; d < c.p.ctcss_fast_ndet; ++d)
-        c.cq_fast[d] = c.cq_fast[kMaxTones + d] = 0.0f;
-    for (int d = 0; d < c.p.ctcss_slow_ndet; ++d)
-        c.cq_slow[d] = c.cq_slow[kMaxTones + d] = 0.0f;
+    if (c.uni) {
+        c.gf_q1 = c.gf_q2 = c.gs_q1 = c.gs_q2 = 0.0f;
+    } else {
+        for (int d = 0; d < c.p.ctcss_fast_ndet; ++d)
+            c.cq_fast[d] = c.cq_fast[kMaxTones + d] = 0.0f;
+        for (int d = 0; d < c.p.ctcss_slow_ndet; ++d)
+            c.cq_slow[d] = c.cq_slow[kMaxTones + d] = 0.0f;
+    }
     c.s.cf_enough = c.s.cf_count = c.s.cf_has_tone = 0;
     c.s.cs_enough = c.s.cs_count = c.s.cs_has_tone = 0;
 }
@@ -262,10 +277,55 @@ __device__ __forceinline__ void ctcss_process(const float* __restrict__ coeff, f
     count = 0;
 }
 
+// The same with one detector per lane: q0 = coeff*q1 - q2 + x in every lane at once; at the end of a window the powers
+// are summed in detector order (the reference's `total += mag` order) by reading the lanes one after the other.
+__device__ __forceinline__ void ctcss_process_lanes(const float coeff, float& q1, float& q2, const int ndet, const int window, int& count, int& enough,
+                                                    int& has_tone, uint64_t& found, uint64_t& not_found, const float sample) {
+    const float q0 = coeff * q1 - q2 + sample;
+    q2 = q1;
+    q1 = q0;
+    count++;
+    if (count < window)
+        return;
+    enough = 1;
+    const float mag = q1 * q1 + q2 * q2 - q1 * q2 * coeff;
+    float total = 0.0f, maxp = 0.0f, target = 0.0f;
+    for (int d = 0; d < ndet; ++d) {
+        const float m = lane_read(mag, d);
+        total += m;
+        if (d == 0) {
+            target = m;
+            maxp = m;
+        } else if (m > maxp) {
+            maxp = m;
+        }
+    }
+    q1 = q2 = 0.0f;
+    const float avg = total / static_cast<float>(ndet);
+    if (target == maxp && target > avg) {
+        has_tone = 1;
+        found++;
+    } else {
+        has_tone = 0;
+        not_found++;
+    }
+    count = 0;
+}
+
 __device__ __forceinline__ void process_audio(Ctx& c, const float sample) {  // squelch.cpp:278-295
     if (!c.p.ctcss_enabled)
         return;
     ChanState& s = c.s;
+    if (c.uni) {
+        if (s.current_state != SQ_CLOSED) {
+            ctcss_process_lanes(c.gs_c, c.gs_q1, c.gs_q2, c.p.ctcss_slow_ndet, c.p.ctcss_slow_window, s.cs_count, s.cs_enough, s.cs_has_tone,
+                                s.cs_found, s.cs_not_found, sample);
+            if (!s.cs_enough)
+                ctcss_process_lanes(c.gf_c, c.gf_q1, c.gf_q2, c.p.ctcss_fast_ndet, c.p.ctcss_fast_window, s.cf_count, s.cf_enough,
+                                    s.cf_has_tone, s.cf_found, s.cf_not_found, sample);
+        }
+        return;
+    }
     if (s.current_state != SQ_CLOSED) {
         ctcss_process(c.cc_slow, c.cq_slow, c.p.ctcss_slow_ndet, c.p.ctcss_slow_window, s.cs_count, s.cs_enough, s.cs_has_tone, s.cs_found,
                       s.cs_not_found, sample);
@@ -301,13 +361,21 @@ __device__ __forceinline__ float fast_atan2(const float y, const float x) {  // 
     return angle;
 }
 
+// kUni: one channel per wave -- all 64 lanes run it in lockstep on the same values.  It is its own instantiation so that
+// the compiler's uniformity analysis sees a row that depends on blockIdx alone: the channel state then sits in scalar
+// registers where it can, the state machine's integer work runs on the scalar unit and its branches are scalar branches.
+template <bool kUni>
 __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
     const int rows = a.nstreams * a.nch;
-    const int row = blockIdx.x * a.lanes_per_wave + threadIdx.x;
-    if (static_cast<int>(threadIdx.x) >= a.lanes_per_wave || row >= rows)
+    constexpr bool uni = kUni;
+    const int row = kUni ? static_cast<int>(blockIdx.x) : static_cast<int>(blockIdx.x) * a.lanes_per_wave + static_cast<int>(threadIdx.x);
+    if ((!kUni && static_cast<int>(threadIdx.x) >= a.lanes_per_wave) || row >= rows)
         return;
     const int stream = row / a.nch, ch = row - stream * a.nch;
     Ctx c;
+    c.uni = uni;
+    c.lane = static_cast<int>(threadIdx.x);
+    c.gf_c = c.gf_q1 = c.gf_q2 = c.gs_c = c.gs_q1 = c.gs_q2 = 0.0f;
     c.s = a.st[row];
     c.p = a.cp[ch];
     const ChanParams& P = c.p;
@@ -319,6 +387,12 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
         c.cc_slow = c.cc_fast + kMaxTones;
         c.cq_fast = a.ctcss_q + (static_cast<size_t>(stream) * a.n_ctcss_rows + P.ctcss_row) * 4 * kMaxTones;
         c.cq_slow = c.cq_fast + 2 * kMaxTones;
+        if (uni) {  // detector `lane` of each set lives in this lane's registers for the whole call
+            if (c.lane < P.ctcss_fast_ndet)
+                c.gf_c = c.cc_fast[c.lane], c.gf_q1 = c.cq_fast[c.lane], c.gf_q2 = c.cq_fast[kMaxTones + c.lane];
+            if (c.lane < P.ctcss_slow_ndet)
+                c.gs_c = c.cc_slow[c.lane], c.gs_q1 = c.cq_slow[c.lane], c.gs_q2 = c.cq_slow[kMaxTones + c.lane];
+        }
     }
 
     float* __restrict__ magrow = a.mag + static_cast<size_t>(row) * a.plane_stride;
@@ -339,32 +413,40 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
     bool batch_open = false;
     uint32_t in_batch = 0, batch = 0;
 
-    // Inputs of step i+2 are requested while step i runs (a two-deep software pipeline in named
-    // registers): the loop's serial chain is arithmetic only.  Index clamped at the row end.
-    const uint32_t last = n - 1;
-    float sx1 = magrow[kAgcExtra], ax1 = magrow[0];
-    float sx2 = magrow[kAgcExtra + 1], ax2 = magrow[1];
-    float2 zx1 = make_float2(0.0f, 0.0f), zx2 = zx1;
-    if (zrow) {
-        zx1 = zrow[0];
-        zx2 = zrow[1];
-    }
+    // Memory traffic is batched four steps at a time: the inputs of steps i0+4 .. i0+7 are requested (16 B per row and
+    // plane) while steps i0 .. i0+3 run, and the four outputs leave as one 16-B store.  A load's wait also waits for every
+    // older store of the wave (vmcnt is in issue order), so a store per step would put the write latency on every step.
+    // n and AGC_EXTRA are multiples of 4: a group never straddles the emitted audio / lookahead boundary.
+    const float4* __restrict__ xg = reinterpret_cast<const float4*>(magrow + kAgcExtra);
+    const float4* __restrict__ ag = reinterpret_cast<const float4*>(magrow);
+    const float4* __restrict__ zg = reinterpret_cast<const float4*>(zrow);  // two complex samples per float4
+    const uint32_t ngroups = n / 4;
+    float4 nx = xg[0], na = ag[0];
+    float4 nz0 = make_float4(0.f, 0.f, 0.f, 0.f), nz1 = nz0;
+    if (zrow)
+        nz0 = zg[0], nz1 = zg[1];
 
     {
-        for (uint32_t i = 0; i < n; ++i) {
-            float x = sx1;  // wavein[j]
-            const float ax = ax1;  // wavein[j - AGC_EXTRA]
-            float re = zx1.x, im = zx1.y;  // iq_in[2*(j-AGC_EXTRA)], [+1]
-            sx1 = sx2;
-            ax1 = ax2;
-            zx1 = zx2;
-            {
-                const uint32_t nxt = (i + 2 <= last) ? i + 2 : last;
-                sx2 = magrow[kAgcExtra + nxt];
-                ax2 = magrow[nxt];
-                if (zrow)
-                    zx2 = zrow[nxt];
-            }
+        for (uint32_t gi = 0; gi < ngroups; ++gi) {
+          const uint32_t i0 = gi * 4;
+          const float4 cx = nx, ca = na, cz0 = nz0, cz1 = nz1;
+          {
+              const uint32_t gn = (gi + 1 < ngroups) ? gi + 1 : gi;
+              nx = xg[gn];
+              na = ag[gn];
+              if (zrow)
+                  nz0 = zg[2 * gn], nz1 = zg[2 * gn + 1];
+          }
+          const float gx[4] = {cx.x, cx.y, cx.z, cx.w}, ga[4] = {ca.x, ca.y, ca.z, ca.w};
+          const float gre[4] = {cz0.x, cz0.z, cz1.x, cz1.z}, gim[4] = {cz0.y, cz0.w, cz1.y, cz1.w};
+          float pend[4] = {0.f, 0.f, 0.f, 0.f};  // waveout of the group, stored together at its end
+          int flushed = 0;                        // outputs [0, flushed) already went out one by one (a fade rewrote them)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const uint32_t i = i0 + static_cast<uint32_t>(m);
+            float x = gx[m];         // wavein[j]
+            const float ax = ga[m];  // wavein[j - AGC_EXTRA]
+            float re = gre[m], im = gim[m];  // iq_in[2*(j-AGC_EXTRA)], [+1]
 
             process_raw(c, x);  // rtl_airband.cpp:529
 
@@ -410,6 +492,11 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
                     }
                 } else if ((c.s.current_state == SQ_CLOSING && c.s.next_state == SQ_CLOSED) ||
                            (c.s.current_state != SQ_LOW_SIGNAL_ABORT && c.s.next_state == SQ_LOW_SIGNAL_ABORT)) {  // last_open_sample
+                    // the fade rewrites the previous 99 outputs: the group's earlier ones have to be in memory first
+#pragma unroll
+                    for (int k = 0; k < m; ++k)
+                        W(kAgcExtra + i0 + k) = pend[k];
+                    flushed = m;
                     float v = W(i);
                     for (int kk = 1; kk < kAgcExtra; ++kk) {
                         v = v * 0.94f;
@@ -474,7 +561,7 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
                 if (iqo)
                     iqo[i] = make_float2(0.0f, 0.0f);
             }
-            W(kAgcExtra + i) = wout;
+            pend[m] = wout;
 
             if (++in_batch == kWaveBatch) {  // rtl_airband.cpp:523,628,667-669
                 a.axc[static_cast<size_t>(row) * a.axc_stride + batch] = batch_open ? MI_SIGNAL : MI_NO_SIGNAL;
@@ -484,6 +571,17 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
                 in_batch = 0;
                 batch++;
             }
+          }
+          if (flushed == 0) {
+              const uint32_t v = kAgcExtra + i0;
+              float* dst = (v < n) ? wmain + v : carry + (v - n);
+              *reinterpret_cast<float4*>(dst) = make_float4(pend[0], pend[1], pend[2], pend[3]);
+          } else {
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                  if (k >= flushed)
+                      W(kAgcExtra + i0 + k) = pend[k];
+          }
         }
     }
 
@@ -497,6 +595,12 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
             zw[v] = zw[n + v];
     }
 
+    if (uni && P.ctcss_enabled) {
+        if (c.lane < P.ctcss_fast_ndet)
+            c.cq_fast[c.lane] = c.gf_q1, c.cq_fast[kMaxTones + c.lane] = c.gf_q2;
+        if (c.lane < P.ctcss_slow_ndet)
+            c.cq_slow[c.lane] = c.gs_q1, c.cq_slow[kMaxTones + c.lane] = c.gs_q2;
+    }
     a.st[row] = c.s;
     if (a.stats) {  // what output.cpp:634-811 reads through the Squelch getters
         mi_channel_stats st;
@@ -592,7 +696,10 @@ hipError_t launch_demod(const DemodArgs& a, hipStream_t s) {
     if (rows == 0 || a.nsteps == 0)
         return hipSuccess;
     const int blocks = (rows + a.lanes_per_wave - 1) / a.lanes_per_wave;
-    hipLaunchKernelGGL(k_demod, dim3(blocks), dim3(64), 0, s, a);
+    if (a.lanes_per_wave == 1)
+        hipLaunchKernelGGL(k_demod<true>, dim3(blocks), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_demod<false>, dim3(blocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
