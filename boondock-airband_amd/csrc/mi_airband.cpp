@@ -133,8 +133,12 @@ int tp_env() {
 constexpr int kTpMinBatches = 8;  // below this the segments are too few to pay for the extra passes
 
 int lanes_per_wave_for(int rows) {
-    // up to 1024 waves (4 per CU) keep one channel each; beyond that pack lanes
-    int lpw = (rows + 1023) / 1024;
+    // up to kUniRows waves keep one channel each (the uniform instantiation of k_demod); beyond that pack lanes
+    static const int uni_rows = [] {
+        const char* e = std::getenv("MI_AIRBAND_UNI_ROWS");
+        return e ? std::max(1, std::atoi(e)) : 4096;
+    }();
+    int lpw = (rows + uni_rows - 1) / uni_rows;
     if (lpw < 1)
         lpw = 1;
     if (lpw > 64)
