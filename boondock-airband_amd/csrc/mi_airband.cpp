@@ -578,6 +578,8 @@ int mi_demod_process_device(mi_demod* h, const void* d_iq, size_t stream_stride_
     const size_t align = 2 * static_cast<size_t>(h->plan.bytes_per_sample);
     if (reinterpret_cast<uintptr_t>(d_iq) % align != 0 || stream_stride_bytes % align != 0)
         return fail(MI_ERR_INVALID, "IQ pointer and stride must be aligned to one complex sample");
+    if (reinterpret_cast<uintptr_t>(d_waveout) % 16 != 0 || (d_iq_out && reinterpret_cast<uintptr_t>(d_iq_out) % 16 != 0))
+        return fail(MI_ERR_INVALID, "d_waveout / d_iq_out must be 16-byte aligned (the kernels store four samples at a time)");
     const size_t need = mi_demod_bytes_needed(h, nbatches);
     if (h->nstreams > 1 && stream_stride_bytes < need)
         return fail(MI_ERR_INVALID, "stream stride shorter than the bytes one call reads");

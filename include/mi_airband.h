@@ -125,7 +125,7 @@ int mi_demod_process(mi_demod* h, const uint8_t* const* iq, int nbatches, float*
 /* Device-resident entry (capture already in HBM; used for bulk replay and by bench.py).
  *   d_iq            device pointer, stream s starts at d_iq + s*stream_stride_bytes
  *   d_waveout       device [nstreams][nch][nbatches*WAVE_BATCH] -- the emitted samples only; the
- *                   AGC_EXTRA lookahead stays in the handle
+ *                   AGC_EXTRA lookahead stays in the handle; 16-byte aligned (so is d_iq_out)
  *   d_iq_out        device [nstreams][nch][nbatches*WAVE_BATCH][2] or NULL
  *   d_axc           device [nstreams][nch][nbatches]
  *   hip_stream      hipStream_t to enqueue on (NULL = default stream); asynchronous */
