@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--noise-only", action="store_true", help="diagnostic: no carriers in the synthetic capture (squelch never opens)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of audio to rank 0 (N>1)")
     ap.add_argument("--diag", action="store_true", help="print the time-parallel path's per-channel counters to stderr")
+    ap.add_argument("--no-overlap", action="store_true", help="do not let consecutive steps overlap (MI_OPT_EARLY_INPUT off)")
     ap.add_argument("--workload", choices=["config2", "config3", "config4"], default="config2",
                     help="config2 = BASELINE configs[1], the bench line (default); config3 = 1 stream x 32 mixed AM/NFM/CTCSS channels at fft 2048; "
                          "config4 = 64 streams x the config-3 plan at fft 512 (extra measurements, not the driver's line)")
@@ -130,12 +131,24 @@ def main():
     pending = [None] * nbuf
 
     h = pkg.Demod(dev, chans, nstreams=nstreams, max_batches=nbat, gpu=local_rank)
+    # The capture is resident before the timed region starts: let the library read it without waiting for the previous
+    # step's tail on the stream, so consecutive steps overlap (stage 1 + core chain of step k+1 under the segment / fix
+    # passes of step k).  --no-overlap times every step in isolation.
+    if not args.no_overlap:
+        h.set_option(pkg.OPT_EARLY_INPUT, 1)
     # prime: the handle's first call consumes AGC_EXTRA extra windows (waveend starts at 0 in the reference)
     h.process_device(d_iq.data_ptr(), nbytes, nbat, d_wo.data_ptr(), d_axc.data_ptr(), hip_stream=stream.cuda_stream)
     base = d_iq.data_ptr() + AGC_EXTRA * hop
     kms = {}  # kernel name -> [total ms over the timed steps, launches]
 
     nstep = [0]
+    prev_timed = [False]
+
+    def add_times(times):
+        for name, ms, launches in times:  # HIP events around the launches, on the launch streams
+            acc = kms.setdefault(name, [0.0, 0])
+            acc[0] += ms
+            acc[1] += launches
 
     def step(timed):
         b = nstep[0] % nbuf
@@ -146,11 +159,10 @@ def main():
         h.process_device(base, nbytes - AGC_EXTRA * hop, nbat, d_wos[b].data_ptr(), d_axc.data_ptr(), hip_stream=stream.cuda_stream)
         if gathering:
             pending[b] = dist.gather(d_wos[b], gather_lists[b], dst=0, async_op=True)
-        if timed:
-            for name, ms, launches in h.kernel_times():  # HIP events around the launches, on the launch streams
-                acc = kms.setdefault(name, [0.0, 0])
-                acc[0] += ms
-                acc[1] += launches
+        # the timings of a step are read one step later, so that reading them does not drain the pipeline
+        if prev_timed[0]:
+            add_times(h.kernel_times(prev=True))
+        prev_timed[0] = timed
 
     for _ in range(args.warmup):
         step(False)
@@ -165,6 +177,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    add_times(h.kernel_times())  # (synchronises with the end of the last step)
+    prev_timed[0] = False
     for b in range(nbuf):  # every gather of the timed steps completes inside the timed region
         if pending[b] is not None:
             pending[b].wait()

@@ -29,6 +29,7 @@ WAVE_BATCH = 2000
 AGC_EXTRA = 100
 
 MOD_AM, MOD_NFM = 0, 1
+OPT_EARLY_INPUT = 1  # MI_OPT_EARLY_INPUT
 SFMT_U8, SFMT_S8, SFMT_S16, SFMT_F32 = 1, 2, 3, 4
 
 MI_OK, MI_ERR_INVALID, MI_ERR_NO_DEVICE, MI_ERR_NOMEM, MI_ERR_HIP, MI_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
@@ -83,7 +84,7 @@ class MixInput(C.Structure):  # mi_mix_input
 ABI_SYMBOLS = [
     "mi_last_error", "mi_device_count", "mi_demod_create", "mi_demod_destroy", "mi_demod_bytes_needed", "mi_demod_bytes_consumed",
     "mi_demod_hop_bytes", "mi_demod_process", "mi_demod_process_device", "mi_demod_get_stats", "mi_demod_state_size",
-    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_tp_debug", "mi_demod_kernel_time","mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
+    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_tp_debug", "mi_demod_kernel_time", "mi_demod_kernel_time_prev", "mi_demod_set_option", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
     "mi_plan_window", "mi_plan_twiddles", "mi_plan_levels", "mi_plan_sincos_lut", "mi_plan_channel", "mi_plan_ctcss_coeffs",
     "mi_iqgen_host", "mi_iqgen_device", "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_is_stereo", "mi_mixer_process_device",
 ]
@@ -118,6 +119,8 @@ def lib():
         L.mi_demod_set_state.argtypes = [vp, vp, sz]
         L.mi_demod_last_path.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mi_demod_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.mi_demod_kernel_time_prev.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.mi_demod_set_option.argtypes = [vp, C.c_int, C.c_int]
         L.mi_demod_tp_debug.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_int)]
         L.mi_demod_read_planes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.mi_demod_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -298,13 +301,18 @@ class Demod:
                                           None if iq is None else iq.ctypes.data_as(C.c_void_p)))
         return mag, iq
 
-    def kernel_times(self):
-        """[(kernel name, total ms, launches)] of the last call (HIP events on the launch streams)."""
+    def set_option(self, option, value):
+        _check(lib().mi_demod_set_option(self._h, option, value))
+
+    def kernel_times(self, prev=False):
+        """[(kernel name, total ms, launches)] of the last call -- or, with prev, of the call before it -- from HIP events
+        on the launch streams."""
         out = []
         i = 0
+        fn = lib().mi_demod_kernel_time_prev if prev else lib().mi_demod_kernel_time
         while True:
             name, ms, n = C.c_char_p(), C.c_float(0), C.c_int(0)
-            if lib().mi_demod_kernel_time(self._h, i, C.byref(name), C.byref(ms), C.byref(n)) != MI_OK:
+            if fn(self._h, i, C.byref(name), C.byref(ms), C.byref(n)) != MI_OK:
                 break
             out.append((name.value.decode(), ms.value, n.value))
             i += 1

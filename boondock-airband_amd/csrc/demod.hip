@@ -764,6 +764,23 @@ __global__ void k_afc(const AfcArgs a) {
 }
 }  // namespace
 
+namespace {
+__global__ void k_move_head(float* __restrict__ dst, const float* __restrict__ src, const size_t plane_stride, const int rows) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rows * kAgcExtra)
+        return;
+    const int r = gid / kAgcExtra, v = gid - r * kAgcExtra;
+    dst[static_cast<size_t>(r) * plane_stride + v] = src[static_cast<size_t>(r) * plane_stride + v];
+}
+}  // namespace
+
+hipError_t launch_move_head(float* dst, const float* src, size_t plane_stride, int rows, hipStream_t s) {
+    if (rows == 0 || dst == src)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_move_head, dim3((rows * kAgcExtra + 255) / 256), dim3(256), 0, s, dst, src, plane_stride, rows);
+    return hipGetLastError();
+}
+
 hipError_t launch_afc(const AfcArgs& a, hipStream_t s) {
     const int rows = a.nstreams * a.nch;
     if (rows == 0)

@@ -100,6 +100,8 @@ struct AfcArgs {
     uint32_t axc_stride;
 };
 hipError_t launch_afc(const AfcArgs& a, hipStream_t s);
+// dst[row][0 .. AGC_EXTRA) = src[row][0 .. AGC_EXTRA) for every plane row (the reference's memmove, rtl_airband.cpp:643-646)
+hipError_t launch_move_head(float* dst, const float* src, size_t plane_stride, int rows, hipStream_t s);
 
 // ---- time-parallel stage 2 (tp.hip) ----
 constexpr uint32_t TP_L = 512;      // steps per segment
@@ -155,7 +157,8 @@ struct TpArgs {
 constexpr uint32_t TP_CHUNK_UNIT = 64000;  // lcm(TP_L = 512, WAVE_BATCH = 2000)
 
 // One chunk in three parts so the caller can put the serial part on its own stream:
-hipError_t launch_tp_front(const TpArgs& a, hipStream_t s);                        // (prologue on the first chunk) + k_tp_full
+hipError_t launch_tp_front(const TpArgs& a, hipStream_t s, bool seed_chain);       // (chain seed on the first chunk) + k_tp_full
+hipError_t launch_tp_audio_head(const TpArgs& a, hipStream_t s);                   // emitted audio [0, AGC_EXTRA) = the previous lookahead
 hipError_t launch_tp_core(const TpArgs& a, hipStream_t s);                         // k_tp_core
 hipError_t launch_tp_seg(const TpArgs& a, hipStream_t s);                          // k_tp_seg (needs core(i) only)
 hipError_t launch_tp_rest(const TpArgs& a, hipStream_t s, hipEvent_t* marks);      // k_tp_scan ... k_tp_finish (needs seg(i) and rest(i-1))

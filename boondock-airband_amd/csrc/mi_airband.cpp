@@ -68,16 +68,30 @@ struct mi_demod {
     bool first_call = true;  // waveend starts at 0: the first batch needs AGC_EXTRA more windows (config.cpp:808)
     size_t plane_stride = 0;
     hipStream_t own_stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    static constexpr int kMaxChunks = 64, kEvPerChunk = 11, kSegStreams = 2;
-    std::vector<hipEvent_t> chunk_ev;  // per chunk: stage1 begin/end, full end, core begin/end, back begin, seg/scan0/fix0/finish ends
-    hipStream_t aux_stream = nullptr;  // carries the serial core chain of the time-parallel path
-    hipStream_t seg_stream[kSegStreams] = {nullptr, nullptr};  // the speculative segment passes (need core(i) only)
-    int tp_chunks = 0;
+    // The time-parallel path keeps two sets of its per-call scratch (magnitude planes, block aggregates, core snapshots,
+    // timing events) and alternates between them: stage 1, the aggregates and the core chain of the next call never touch
+    // what the segment and fix passes of the previous call still read, so consecutive calls overlap (see enqueue()).
+    // `cur` is the set of the last call; the serial path stays on it.
+    int cur = 0;
+    hipEvent_t ev[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    static constexpr int kMaxChunks = 64, kEvPerChunk = 12, kSegStreams = 1;
+    std::vector<hipEvent_t> chunk_ev[2];  // per chunk: stage1 begin/end, full end, core begin/end, seg begin/end, scan0/fix0/finish ends, rest begin
+    hipStream_t aux_stream = nullptr;    // carries the serial core chain of the time-parallel path
+    hipStream_t front_stream = nullptr;  // stage 1 + aggregates of the time-parallel path
+    hipEvent_t ev_entry = nullptr;       // recorded on the caller's stream when a call starts
+    hipEvent_t ev_head = nullptr;        // ... and after the audio head of the call has been written
+    float* d_mag_set[2] = {nullptr, nullptr};  // d_mag aliases d_mag_set[cur]
+    uint32_t head_off = 0;     // plane index where the AGC_EXTRA carried samples of every row live (0 after a serial call)
+    bool early_input = false;  // MI_OPT_EARLY_INPUT: the IQ of a call is valid when the call is made
+    bool chain_live = false;   // d_core_carry holds the chain state at the end of the previous call (it was time-parallel)
+    hipStream_t seg_stream[kSegStreams] = {nullptr};  // the speculative segment passes (need core(i) only)
+    int tp_chunks[2] = {0, 0};
     mi::TpCore* d_core_carry = nullptr;
     float* d_full0 = nullptr;
     float* d_afc_spec = nullptr;  // [nstreams][fft_size] squared spectrum of the last window of a batch (AFC handles only)
-    bool ev_valid = false;
+    uint64_t set_seq[2] = {0, 0};  // call number that last used each event set (0 = never)
+    uint64_t call_seq = 0;
+    int set_path[2] = {0, 0};
     // device memory
     float* d_window = nullptr;
     float* d_tw = nullptr;
@@ -105,15 +119,15 @@ struct mi_demod {
     bool tp_eligible = false;
     int last_path = 0;  // 0 = serial kernel, 1 = time-parallel
     int* d_rows = nullptr;
-    unsigned* d_xmax = nullptr;
-    float *d_blk_fe = nullptr, *d_blk_fm = nullptr, *d_blk_x0 = nullptr, *d_blk_xm = nullptr;
-    mi::TpCore* d_core = nullptr;
+    unsigned* d_xmax[2] = {nullptr, nullptr};
+    float *d_blk_fe[2] = {nullptr, nullptr}, *d_blk_fm[2] = {nullptr, nullptr}, *d_blk_x0[2] = {nullptr, nullptr}, *d_blk_xm[2] = {nullptr, nullptr};
+    mi::TpCore* d_core[2] = {nullptr, nullptr};
     int* d_rec = nullptr;
     int* d_tstart = nullptr;
     int* d_need = nullptr;
     mi::TpFinal* d_fin = nullptr;
     int* d_diag = nullptr;
-    uint32_t last_nseg = 0;
+    uint32_t last_nseg[2] = {0, 0};
     size_t tp_max_blk = 0, tp_max_seg = 0;
 };
 
@@ -169,7 +183,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     ca.n_iq_rows = h->plan.n_iq_rows;
     const int env = tp_env();
     const bool use_tp = h->tp_eligible && env != 0 && (env == 1 || nbatches >= kTpMinBatches);
-    ca.xmax = use_tp ? h->d_xmax : nullptr;
+    ca.xmax = nullptr;  // (the time-parallel branch points it at its scratch set)
 
     mi::DemodArgs da{};
     da.nstreams = h->nstreams;
@@ -199,12 +213,28 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     da.fm_quadri = h->plan.dev.fm_quadri;
     da.lanes_per_wave = lanes_per_wave_for(h->rows);
 
-    h->tp_chunks = 0;
+    // the serial kernels expect the carried AGC_EXTRA samples of every row at the front of the planes they work on
+    auto head_in_place = [&]() -> int {
+        if (h->head_off != 0) {
+            HIP_TRY(mi::launch_move_head(h->d_mag, h->d_mag + h->head_off, h->plane_stride, h->rows, s));
+            h->head_off = 0;
+        }
+        return MI_OK;
+    };
+    hipEvent_t* evc = h->ev[h->cur];  // (the time-parallel branch switches to the other set)
     if (use_tp) {
-        // ---- time-parallel stage 2, pipelined over chunks of the call ----
+        // ---- time-parallel stage 2, pipelined over chunks of the call and across calls ----
         // The exact core chain (k_tp_core) is serial per channel and latency bound on 8 waves; everything else is wide.
-        // Chunk i's core kernel runs on the handle's aux stream while stage 1 + k_tp_full of chunk i+1 and the
-        // segment / scan / fix passes of chunk i-1 run on the caller's stream.
+        //   front stream : head carry, then per chunk stage 1 + k_tp_full           (needs the IQ; chunk 0's k_tp_full needs
+        //                                                                             the chain state at the call start)
+        //   aux stream   : k_tp_core(i) as soon as chunk i's aggregates exist         (one chain across chunks AND calls)
+        //   seg streams  : k_tp_seg(i) as soon as core(i) is done and the previous call has left its final state
+        //   caller's     : audio head, then scan / fix / redo / finish of chunk i after seg(i) and the chain of chunk i-1
+        // With MI_OPT_EARLY_INPUT the front and aux streams do not wait for the caller's stream, i.e. for the segment
+        // and fix passes of the previous call: consecutive calls overlap and the core chain runs back to back.
+        const int q = h->cur ^ 1;  // the scratch set of this call
+        float* const planes = h->d_mag_set[q];
+        const bool overlap = h->early_input && h->chain_live && !h->first_call;
         const uint32_t n = da.nsteps;
         const uint32_t units = n / mi::TP_CHUNK_UNIT;
         // Chunk sizes grow geometrically: a short first chunk gets the serial core chain going early (its stage 1 +
@@ -226,10 +256,10 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             w = 1.0;
             for (int i = 0; i < want; ++i, w *= ratio) {
                 acc += w;
-                uint32_t b = (i == want - 1) ? units : static_cast<uint32_t>(acc / total * units + 0.5);
-                b = std::max(b, bound.back() + 1);
-                b = std::min(b, units - static_cast<uint32_t>(want - 1 - i));
-                bound.push_back(b);
+                uint32_t bd = (i == want - 1) ? units : static_cast<uint32_t>(acc / total * units + 0.5);
+                bd = std::max(bd, bound.back() + 1);
+                bd = std::min(bd, units - static_cast<uint32_t>(want - 1 - i));
+                bound.push_back(bd);
             }
         } else {
             bound.push_back(0);
@@ -237,11 +267,13 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         const int C = static_cast<int>(bound.size()) - 1;
         if (C > mi_demod::kMaxChunks)
             return fail(MI_ERR_INVALID, "too many chunks");
-        while (static_cast<int>(h->chunk_ev.size()) < C * mi_demod::kEvPerChunk) {
+        std::vector<hipEvent_t>& cev = h->chunk_ev[q];
+        while (static_cast<int>(cev.size()) < C * mi_demod::kEvPerChunk) {
             hipEvent_t e = nullptr;
             HIP_TRY(hipEventCreate(&e));
-            h->chunk_ev.push_back(e);
+            cev.push_back(e);
         }
+        evc = h->ev[q];
         mi::TpArgs ta{};
         ta.rows = h->d_rows;
         ta.nrows = h->rows;
@@ -250,7 +282,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.nbatches = da.nbatches;
         ta.nblk = n / 16;
         ta.nseg = (n + mi::TP_L - 1) / mi::TP_L;
-        ta.mag = h->d_mag;
+        ta.mag = planes;
         ta.plane_stride = h->plane_stride;
         ta.wmain = d_wmain;
         ta.wmain_stride = wmain_stride;
@@ -259,12 +291,12 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.cp = h->d_cp;
         ta.st = h->d_state;
         ta.stats = h->d_stats;
-        ta.xmax = h->d_xmax;
-        ta.blk_fe = h->d_blk_fe;
-        ta.blk_fm = h->d_blk_fm;
-        ta.blk_x0 = h->d_blk_x0;
-        ta.blk_xm = h->d_blk_xm;
-        ta.core = h->d_core;
+        ta.xmax = h->d_xmax[q];
+        ta.blk_fe = h->d_blk_fe[q];
+        ta.blk_fm = h->d_blk_fm[q];
+        ta.blk_x0 = h->d_blk_x0[q];
+        ta.blk_xm = h->d_blk_xm[q];
+        ta.core = h->d_core[q];
         ta.core_carry = h->d_core_carry;
         ta.full0 = h->d_full0;
         ta.rec = h->d_rec;
@@ -273,7 +305,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.need = h->d_need;
         ta.fin = h->d_fin;
         ta.diag = h->d_diag;
-        h->last_nseg = ta.nseg;
+        h->last_nseg[q] = ta.nseg;
         auto chunk = [&](int i) {
             mi::TpArgs c = ta;
             c.step0 = bound[static_cast<size_t>(i)] * mi::TP_CHUNK_UNIT;
@@ -289,6 +321,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             return c;
         };
         const bool first_call = h->first_call;
+        hipStream_t fs = h->front_stream;
         auto stage1 = [&](const mi::TpArgs& c) -> hipError_t {  // the windows whose magnitudes are the chunk's squelch samples
             mi::ChannelizeArgs cc = ca;
             const uint32_t f0 = first_call ? (c.first_chunk ? 0u : c.step0 + mi::kAgcExtra) : c.step0;
@@ -297,27 +330,52 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             cc.valid_bytes = ca.valid_bytes - static_cast<size_t>(f0) * ca.hop_bytes;
             cc.nfft = f1 - f0;
             cc.plane_off = ca.plane_off + f0;
-            return mi::launch_channelize(cc, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, s);
+            cc.mag = planes;
+            cc.xmax = h->d_xmax[q];
+            return mi::launch_channelize(cc, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, fs);
         };
-        auto ev = [&](int i, int k) { return h->chunk_ev[static_cast<size_t>(i) * mi_demod::kEvPerChunk + k]; };
-        HIP_TRY(hipMemsetAsync(h->d_xmax, 0, static_cast<size_t>(h->rows) * sizeof(unsigned), s));
-        HIP_TRY(hipMemsetAsync(h->d_diag, 0, static_cast<size_t>(h->rows) * 8 * sizeof(int), s));
-        HIP_TRY(hipEventRecord(h->ev[0], s));
-        HIP_TRY(hipEventRecord(h->ev[1], s));
-        HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev[1], 0));  // the aux stream starts after everything queued so far
-        auto front = [&](int i) -> int {
+        auto ev = [&](int i, int k) { return cev[static_cast<size_t>(i) * mi_demod::kEvPerChunk + k]; };
+        HIP_TRY(hipEventRecord(h->ev_entry, s));
+        HIP_TRY(hipEventRecord(evc[0], s));
+        HIP_TRY(hipEventRecord(evc[1], s));
+        HIP_TRY(mi::launch_tp_audio_head(ta, s));
+        HIP_TRY(hipEventRecord(h->ev_head, s));  // the previous call is complete and its lookahead has been taken over
+        if (!overlap)
+            HIP_TRY(hipStreamWaitEvent(fs, h->ev_entry, 0));  // stage 1 honours the caller's stream order
+        else if (h->set_seq[q])
+            HIP_TRY(hipStreamWaitEvent(fs, h->ev[q][2], 0));  // the call before the previous one has left this scratch set
+        // the carried samples of the previous call (wherever they are) become the head of this call's planes
+        HIP_TRY(mi::launch_move_head(planes, h->d_mag + h->head_off, h->plane_stride, h->rows, fs));
+        HIP_TRY(hipMemsetAsync(h->d_xmax[q], 0, static_cast<size_t>(h->rows) * sizeof(unsigned), fs));
+        // Stage 1 + aggregates of every chunk first: nothing else feeds them.  When calls overlap, k_tp_full of chunk 0 has
+        // to wait for the end of the previous call's chain (it starts from its full_): stage 1 runs one chunk ahead of the
+        // aggregates so that the wait does not hold up the stage 1 the chain needs next.
+        const int lead = overlap ? 1 : 0;
+        auto do_stage1 = [&](int i) -> int {
             const mi::TpArgs c = chunk(i);
-            HIP_TRY(hipEventRecord(ev(i, 0), s));
+            HIP_TRY(hipEventRecord(ev(i, 0), fs));
             HIP_TRY(stage1(c));
-            HIP_TRY(hipEventRecord(ev(i, 1), s));
-            HIP_TRY(mi::launch_tp_front(c, s));  // (on its own stream it competes with the next chunk's stage 1: measured slower)
-            HIP_TRY(hipEventRecord(ev(i, 2), s));
+            HIP_TRY(hipEventRecord(ev(i, 1), fs));
             return MI_OK;
         };
-        for (int i = 0; i < C; ++i) {  // stage 1 + aggregates of every chunk first: nothing else feeds them
-            int rc = front(i);
+        int staged = 0;  // chunks whose stage 1 has been queued
+        for (; staged < std::min(lead + 1, C); ++staged) {
+            int rc = do_stage1(staged);
             if (rc != MI_OK)
                 return rc;
+        }
+        for (int i = 0; i < C; ++i) {
+            if (i >= staged) {
+                int rc = do_stage1(staged++);
+                if (rc != MI_OK)
+                    return rc;
+            }
+            const mi::TpArgs c = chunk(i);
+            if (i == 0 && overlap)  // the chain state at the end of the previous call
+                HIP_TRY(hipStreamWaitEvent(fs, h->chunk_ev[h->cur][static_cast<size_t>(h->tp_chunks[h->cur] - 1) * mi_demod::kEvPerChunk + 4], 0));
+            HIP_TRY(hipEventRecord(ev(i, 11), fs));
+            HIP_TRY(mi::launch_tp_front(c, fs, /*seed_chain=*/!overlap));
+            HIP_TRY(hipEventRecord(ev(i, 2), fs));
         }
         for (int i = 0; i < C; ++i) {
             const mi::TpArgs c = chunk(i);
@@ -326,8 +384,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             HIP_TRY(mi::launch_tp_core(c, h->aux_stream));
             HIP_TRY(hipEventRecord(ev(i, 4), h->aux_stream));
             hipStream_t ss = h->seg_stream[i % mi_demod::kSegStreams];
-            if (i < mi_demod::kSegStreams)
-                HIP_TRY(hipStreamWaitEvent(ss, h->ev[1], 0));  // not before the work queued ahead of this call
+            HIP_TRY(hipStreamWaitEvent(ss, h->ev_head, 0));  // the final state and records of the previous call; the caller's order
             HIP_TRY(hipStreamWaitEvent(ss, ev(i, 4), 0));
             HIP_TRY(hipEventRecord(ev(i, 5), ss));
             HIP_TRY(mi::launch_tp_seg(c, ss));
@@ -337,12 +394,16 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             hipEvent_t marks[mi::TP_REST_MARKS] = {ev(i, 7), ev(i, 8), ev(i, 9)};
             HIP_TRY(mi::launch_tp_rest(c, s, marks));
         }
-        h->tp_chunks = C;
+        h->tp_chunks[q] = C;
+        h->cur = q;
+        h->d_mag = planes;
+        h->head_off = n;  // (first call: the planes hold AGC_EXTRA + n samples, the last AGC_EXTRA start at n as well)
+        h->chain_live = true;
     } else if (h->plan.any_afc) {
         // AFC (rtl_airband.cpp:180-251): the bins stage 1 picks in batch b+1 depend on the squelch outcome of batch b, so
         // the batches are enqueued one at a time -- stage 1, channel loop, AFC::finalize -- with the bin table and the
         // previous indicator resident in ChanState: no host round trip inside the call.
-        HIP_TRY(hipEventRecord(h->ev[0], s));
+        HIP_TRY(hipEventRecord(evc[0], s));
         size_t f0 = 0;  // first window of the batch, relative to the call
         for (int b = 0; b < nbatches; ++b) {
             const bool first = h->first_call && b == 0;
@@ -356,7 +417,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             cb.afc_spec = h->d_afc_spec;
             HIP_TRY(mi::launch_channelize(cb, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, s));
             if (b == 0)
-                HIP_TRY(hipEventRecord(h->ev[1], s));
+                HIP_TRY(hipEventRecord(evc[1], s));
             mi::DemodArgs db = da;
             db.nsteps = mi::kWaveBatch;
             db.nbatches = 1;
@@ -377,14 +438,19 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             f0 += nf;
         }
     } else {
-        HIP_TRY(hipEventRecord(h->ev[0], s));
+        int rc = head_in_place();
+        if (rc != MI_OK)
+            return rc;
+        h->chain_live = false;  // k_demod does not maintain the time-parallel chain state
+        HIP_TRY(hipEventRecord(evc[0], s));
         HIP_TRY(mi::launch_channelize(ca, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, s));
-        HIP_TRY(hipEventRecord(h->ev[1], s));
+        HIP_TRY(hipEventRecord(evc[1], s));
         HIP_TRY(mi::launch_demod(da, s));
     }
     h->last_path = use_tp ? 1 : 0;
-    HIP_TRY(hipEventRecord(h->ev[2], s));
-    h->ev_valid = true;
+    HIP_TRY(hipEventRecord(evc[2], s));
+    h->set_seq[h->cur] = ++h->call_seq;
+    h->set_path[h->cur] = h->last_path;
     h->first_call = false;
     return MI_OK;
 }
@@ -408,22 +474,30 @@ void mi_demod_destroy(mi_demod* h) {
     if (!h)
         return;
     (void)hipSetDevice(h->gpu);
-    void* ptrs[] = {h->d_window, h->d_tw,   h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_mag,   h->d_cplx, h->d_carry,
+    void* ptrs[] = {h->d_window, h->d_tw,   h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_mag_set[0], h->d_cplx, h->d_carry,
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc,
-                    h->d_rows,   h->d_xmax, h->d_blk_fe, h->d_blk_fm, h->d_blk_x0, h->d_blk_xm, h->d_core, h->d_rec, h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_afc_spec};
+                    h->d_rows,   h->d_xmax[0], h->d_xmax[1], h->d_blk_fe[0], h->d_blk_fm[0], h->d_blk_x0[0], h->d_blk_xm[0], h->d_blk_fe[1], h->d_blk_fm[1], h->d_blk_x0[1], h->d_blk_xm[1], h->d_core[0], h->d_core[1], h->d_mag_set[1], h->d_rec, h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_afc_spec};
     for (void* p : ptrs)
         if (p)
             (void)hipFree(p);
     if (h->h_pin)
         (void)hipHostFree(h->h_pin);
-    for (hipEvent_t e : h->ev)
-        if (e)
-            (void)hipEventDestroy(e);
-    for (hipEvent_t e : h->chunk_ev)
-        if (e)
-            (void)hipEventDestroy(e);
+    for (int q = 0; q < 2; ++q) {
+        for (hipEvent_t e : h->ev[q])
+            if (e)
+                (void)hipEventDestroy(e);
+        for (hipEvent_t e : h->chunk_ev[q])
+            if (e)
+                (void)hipEventDestroy(e);
+    }
+    if (h->ev_entry)
+        (void)hipEventDestroy(h->ev_entry);
+    if (h->ev_head)
+        (void)hipEventDestroy(h->ev_head);
     if (h->aux_stream)
         (void)hipStreamDestroy(h->aux_stream);
+    if (h->front_stream)
+        (void)hipStreamDestroy(h->front_stream);
     for (hipStream_t ss : h->seg_stream)
         if (ss)
             (void)hipStreamDestroy(ss);
@@ -483,9 +557,20 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
 
     TRY_OR_BAIL(hipSetDevice(gpu));
     TRY_OR_BAIL(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
-    for (auto& ev : h->ev)
-        TRY_OR_BAIL(hipEventCreate(&ev));
-    TRY_OR_BAIL(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    for (auto& evs : h->ev)
+        for (hipEvent_t& ev : evs)
+            TRY_OR_BAIL(hipEventCreate(&ev));
+    TRY_OR_BAIL(hipEventCreate(&h->ev_entry));
+    TRY_OR_BAIL(hipEventCreate(&h->ev_head));
+    {
+        // HIP multiplexes its streams onto a few hardware queues; two streams that share one run their kernels one after
+        // the other.  The core chain must never queue behind a wide pass, so it gets the highest stream priority (its
+        // own queue class), and the wide passes share as few other streams as the pipeline needs.
+        int lo_prio = 0, hi_prio = 0;
+        TRY_OR_BAIL(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+        TRY_OR_BAIL(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, hi_prio));
+    }
+    TRY_OR_BAIL(hipStreamCreateWithFlags(&h->front_stream, hipStreamNonBlocking));
     for (hipStream_t& ss : h->seg_stream)
         TRY_OR_BAIL(hipStreamCreateWithFlags(&ss, hipStreamNonBlocking));
     const size_t rows = static_cast<size_t>(h->rows);
@@ -496,7 +581,8 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     TRY_OR_BAIL(dalloc(&h->d_cos, 257));
     TRY_OR_BAIL(dalloc(&h->d_cp, static_cast<size_t>(nch)));
     TRY_OR_BAIL(dalloc(&h->d_state, rows));
-    TRY_OR_BAIL(dalloc(&h->d_mag, rows * h->plane_stride));
+    TRY_OR_BAIL(dalloc(&h->d_mag_set[0], rows * h->plane_stride));
+    h->d_mag = h->d_mag_set[0];
     TRY_OR_BAIL(dalloc(&h->d_cplx, static_cast<size_t>(nstreams) * p.n_iq_rows * h->plane_stride));
     TRY_OR_BAIL(dalloc(&h->d_carry, rows * mi::kAgcExtra));
     TRY_OR_BAIL(dalloc(&h->d_ring, rows * mi::kSquelchRing));
@@ -529,12 +615,16 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
             ident[i] = static_cast<int>(i);
         TRY_OR_BAIL(dalloc(&h->d_rows, rows));
         TRY_OR_BAIL(hipMemcpy(h->d_rows, ident.data(), rows * sizeof(int), hipMemcpyHostToDevice));
-        TRY_OR_BAIL(dalloc(&h->d_xmax, rows));
-        TRY_OR_BAIL(dalloc(&h->d_blk_fe, rows * h->tp_max_blk));
-        TRY_OR_BAIL(dalloc(&h->d_blk_fm, rows * h->tp_max_blk));
-        TRY_OR_BAIL(dalloc(&h->d_blk_x0, rows * h->tp_max_blk));
-        TRY_OR_BAIL(dalloc(&h->d_blk_xm, rows * h->tp_max_blk));
-        TRY_OR_BAIL(dalloc(&h->d_core, rows * (h->tp_max_seg + 1)));
+        TRY_OR_BAIL(dalloc(&h->d_mag_set[1], rows * h->plane_stride));
+        TRY_OR_BAIL(hipMemset(h->d_mag_set[1], 0, rows * h->plane_stride * 4));
+        for (int q = 0; q < 2; ++q) {
+            TRY_OR_BAIL(dalloc(&h->d_xmax[q], rows));
+            TRY_OR_BAIL(dalloc(&h->d_blk_fe[q], rows * h->tp_max_blk));
+            TRY_OR_BAIL(dalloc(&h->d_blk_fm[q], rows * h->tp_max_blk));
+            TRY_OR_BAIL(dalloc(&h->d_blk_x0[q], rows * h->tp_max_blk));
+            TRY_OR_BAIL(dalloc(&h->d_blk_xm[q], rows * h->tp_max_blk));
+            TRY_OR_BAIL(dalloc(&h->d_core[q], rows * (h->tp_max_seg + 1)));
+        }
         TRY_OR_BAIL(dalloc(&h->d_rec, static_cast<size_t>(mi::TP_NREC) * rows * h->tp_max_seg));
         TRY_OR_BAIL(dalloc(&h->d_tstart, rows * h->tp_max_seg * 8));
         TRY_OR_BAIL(dalloc(&h->d_need, rows * h->tp_max_seg));
@@ -685,7 +775,7 @@ int mi_demod_get_state(mi_demod* h, void* buf, size_t len) {
     HIP_TRY(pull(h->d_carry, rows * mi::kAgcExtra * 4));
     HIP_TRY(pull(h->d_ring, rows * mi::kSquelchRing * 4));
     HIP_TRY(pull(h->d_ctcss_q, static_cast<size_t>(h->nstreams) * h->plan.n_ctcss_rows * 4 * mi::kMaxTones * 4));
-    HIP_TRY(hipMemcpy2D(o, mi::kAgcExtra * 4, h->d_mag, h->plane_stride * 4, mi::kAgcExtra * 4, rows, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(o, mi::kAgcExtra * 4, h->d_mag + h->head_off, h->plane_stride * 4, mi::kAgcExtra * 4, rows, hipMemcpyDeviceToHost));
     o += rows * mi::kAgcExtra * 4;
     const size_t zrows = static_cast<size_t>(h->nstreams) * h->plan.n_iq_rows;
     if (zrows)
@@ -719,6 +809,8 @@ int mi_demod_set_state(mi_demod* h, const void* buf, size_t len) {
     HIP_TRY(push(h->d_ring, rows * mi::kSquelchRing * 4));
     HIP_TRY(push(h->d_ctcss_q, static_cast<size_t>(h->nstreams) * h->plan.n_ctcss_rows * 4 * mi::kMaxTones * 4));
     HIP_TRY(hipMemcpy2D(h->d_mag, h->plane_stride * 4, o, mi::kAgcExtra * 4, mi::kAgcExtra * 4, rows, hipMemcpyHostToDevice));
+    h->head_off = 0;
+    h->chain_live = false;  // the chain state of the time-parallel path is re-seeded from the restored ChanState
     o += rows * mi::kAgcExtra * 4;
     const size_t zrows = static_cast<size_t>(h->nstreams) * h->plan.n_iq_rows;
     if (zrows)
@@ -752,10 +844,10 @@ int mi_demod_tp_debug(mi_demod* h, int row, float* core4, int max_entries, int* 
     HIP_TRY(hipSetDevice(h->gpu));
     HIP_TRY(hipDeviceSynchronize());
     if (nseg)
-        *nseg = static_cast<int>(h->last_nseg);
+        *nseg = static_cast<int>(h->last_nseg[h->cur]);
     if (core4) {
-        const size_t n = std::min<size_t>(static_cast<size_t>(max_entries), h->last_nseg + 1);
-        HIP_TRY(hipMemcpy(core4, h->d_core + static_cast<size_t>(row) * (h->last_nseg + 1), n * sizeof(mi::TpCore), hipMemcpyDeviceToHost));
+        const size_t n = std::min<size_t>(static_cast<size_t>(max_entries), h->last_nseg[h->cur] + 1);
+        HIP_TRY(hipMemcpy(core4, h->d_core[h->cur] + static_cast<size_t>(row) * (h->last_nseg[h->cur] + 1), n * sizeof(mi::TpCore), hipMemcpyDeviceToHost));
     }
     if (diag4) {  // [0..3] scan rounds, [4..7] core-chain blocks: in accepted runs, single O(1), stepped, failed hypotheses
         HIP_TRY(hipMemcpy(diag4, h->d_diag + static_cast<size_t>(row) * 4, 4 * sizeof(int), hipMemcpyDeviceToHost));
@@ -780,32 +872,38 @@ int mi_demod_read_planes(mi_demod* h, int stream, int ch, int first, int count, 
     return MI_OK;
 }
 
-int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms_total, int* launches) {
-    if (!h || !h->ev_valid || index < 0)
-        return fail(MI_ERR_INVALID, "no call has been timed yet");
+// timing of the last call (age 0) or of the call before it (age 1, only while its event set has not been reused)
+static int kernel_time_of(mi_demod* h, int age, int index, const char** name, float* ms_total, int* launches) {
+    if (!h || index < 0 || age < 0 || age > 1)
+        return fail(MI_ERR_INVALID, "bad argument");
+    const int q = h->cur ^ age;
+    if (!h->set_seq[q] || (age == 1 && h->set_seq[q] + 1 != h->set_seq[h->cur]))
+        return fail(MI_ERR_INVALID, "that call has not been timed (or its events were reused)");
     HIP_TRY(hipSetDevice(h->gpu));
-    HIP_TRY(hipEventSynchronize(h->ev[2]));
+    hipEvent_t* evq = h->ev[q];
+    HIP_TRY(hipEventSynchronize(evq[2]));
     float t = 0.f;
     int n = 1;
     const char* nm = nullptr;
-    if (h->last_path == 0) {
+    if (h->set_path[q] == 0) {
         if (index > 1)
             return fail(MI_ERR_INVALID, "kernel index out of range");
         nm = index == 0 ? "k_channelize" : "k_demod";
-        HIP_TRY(hipEventElapsedTime(&t, h->ev[index], h->ev[index + 1]));
+        HIP_TRY(hipEventElapsedTime(&t, evq[index], evq[index + 1]));
     } else {
-        // per chunk events: 0 stage1 begin, 1 stage1 end, 2 k_tp_full end, 3 core begin, 4 core end (aux stream), 5 seg begin,
-        // 6 seg end (segment stream), 10 scan#0 begin, 7 scan#0 end, 8 fix#0 end, 9 finish end
+        // per chunk events: 0 stage1 begin, 1 stage1 end, 2 k_tp_full end (front stream), 3 core begin, 4 core end (aux stream),
+        // 5 seg begin, 6 seg end (segment stream), 10 scan#0 begin, 7 scan#0 end, 8 fix#0 + redo#0 end, 9 finish end (caller's stream), 11 k_tp_full begin
         static const char* const names[] = {"k_channelize", "k_tp_full", "k_tp_core", "k_tp_seg", "k_tp_scan#0", "k_tp_fix#0", "k_tp_rest"};
-        static const int from[] = {0, 1, 3, 5, 10, 7, 8}, to[] = {1, 2, 4, 6, 7, 8, 9};
+        static const int from[] = {0, 11, 3, 5, 10, 7, 8}, to[] = {1, 2, 4, 6, 7, 8, 9};
         if (index > 6)
             return fail(MI_ERR_INVALID, "kernel index out of range");
         nm = names[index];
-        n = h->tp_chunks;
-        for (int i = 0; i < h->tp_chunks; ++i) {
+        n = h->tp_chunks[q];
+        const std::vector<hipEvent_t>& cev = h->chunk_ev[q];
+        for (int i = 0; i < n; ++i) {
             float d = 0.f;
-            HIP_TRY(hipEventElapsedTime(&d, h->chunk_ev[static_cast<size_t>(i) * mi_demod::kEvPerChunk + from[index]],
-                                        h->chunk_ev[static_cast<size_t>(i) * mi_demod::kEvPerChunk + to[index]]));
+            HIP_TRY(hipEventElapsedTime(&d, cev[static_cast<size_t>(i) * mi_demod::kEvPerChunk + from[index]],
+                                        cev[static_cast<size_t>(i) * mi_demod::kEvPerChunk + to[index]]));
             t += d;
         }
     }
@@ -818,18 +916,27 @@ int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms_to
     return MI_OK;
 }
 
+int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms_total, int* launches) {
+    return kernel_time_of(h, 0, index, name, ms_total, launches);
+}
+
+int mi_demod_kernel_time_prev(mi_demod* h, int index, const char** name, float* ms_total, int* launches) {
+    return kernel_time_of(h, 1, index, name, ms_total, launches);
+}
+
 int mi_demod_last_kernel_ms(mi_demod* h, float* channelize_ms, float* demod_ms) {
-    if (!h || !h->ev_valid)
+    if (!h || !h->set_seq[h->cur])
         return fail(MI_ERR_INVALID, "no call has been timed yet");
     HIP_TRY(hipSetDevice(h->gpu));
-    HIP_TRY(hipEventSynchronize(h->ev[2]));
+    hipEvent_t* evq = h->ev[h->cur];
+    HIP_TRY(hipEventSynchronize(evq[2]));
     float a = 0.f, b = 0.f;
     if (h->last_path == 0) {
-        HIP_TRY(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+        HIP_TRY(hipEventElapsedTime(&a, evq[0], evq[1]));
+        HIP_TRY(hipEventElapsedTime(&b, evq[1], evq[2]));
     } else {  // pipelined: stage 1 summed over the chunks, stage 2 = the rest of the call's wall time on the stream
         float total = 0.f;
-        HIP_TRY(hipEventElapsedTime(&total, h->ev[0], h->ev[2]));
+        HIP_TRY(hipEventElapsedTime(&total, evq[0], evq[2]));
         int rc = mi_demod_kernel_time(h, 0, nullptr, &a, nullptr);
         if (rc != MI_OK)
             return rc;
@@ -840,6 +947,18 @@ int mi_demod_last_kernel_ms(mi_demod* h, float* channelize_ms, float* demod_ms) 
     if (demod_ms)
         *demod_ms = b;
     return MI_OK;
+}
+
+int mi_demod_set_option(mi_demod* h, int option, int value) {
+    if (!h)
+        return fail(MI_ERR_INVALID, "NULL handle");
+    switch (option) {
+        case MI_OPT_EARLY_INPUT:
+            h->early_input = value != 0;
+            return MI_OK;
+        default:
+            return fail(MI_ERR_INVALID, "unknown option");
+    }
 }
 
 // ---------------- host-only plan views ----------------

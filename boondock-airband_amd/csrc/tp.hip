@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64) void k_tp_full(const TpArgs a) {
     const uint32_t tw = t0 > TP_W1 ? t0 - TP_W1 : 0;
     float lo, hi;
     if (tw == 0) {
-        lo = hi = a.st[row].pre_full;  // the true value: exact from the first step
+        lo = hi = a.full0[r];  // the true value at the call start: exact from the first step
     } else {
         lo = 0.0f;
         // any earlier value of full_ is bounded by its value at the start of the call and the largest sample so far
@@ -432,11 +432,12 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
         t.nf = nf, t.cap = cap, t.c = c, t.full = full;
         core[(a.blk1 + bps - 1) / bps] = t;  // = the next chunk's first boundary, or the end of the call
         a.core_carry[r] = t;
-        if (a.diag) {
-            a.diag[a.nrows * 4 + r * 4 + 0] += n_run;
-            a.diag[a.nrows * 4 + r * 4 + 1] += n_single;
-            a.diag[a.nrows * 4 + r * 4 + 2] += n_step;
-            a.diag[a.nrows * 4 + r * 4 + 3] += n_fail;
+        if (a.diag) {  // counters of the call: the first chunk starts them
+            int* d = a.diag + a.nrows * 4 + r * 4;
+            d[0] = (a.first_chunk ? 0 : d[0]) + n_run;
+            d[1] = (a.first_chunk ? 0 : d[1]) + n_single;
+            d[2] = (a.first_chunk ? 0 : d[2]) + n_step;
+            d[3] = (a.first_chunk ? 0 : d[3]) + n_fail;
         }
     }
 }
@@ -1189,8 +1190,10 @@ __global__ __launch_bounds__(64) void k_tp_scan(const TpArgs a) {
         f.d_open = sum_open;
         f.d_flappy = sum_flappy;
         a.fin[r] = f;
-        if (a.diag)
-            a.diag[r * 4 + (a.scan_round & 3)] += nbad;
+        if (a.diag) {  // unaccepted segments per scan round, summed over the chunks of the call
+            int* d = a.diag + r * 4 + (a.scan_round & 3);
+            *d = (a.first_chunk ? 0 : *d) + nbad;
+        }
     }
 }
 
@@ -1348,11 +1351,7 @@ __global__ __launch_bounds__(64) void k_tp_finish(const TpArgs a) {
     }
     for (int off = 32; off > 0; off >>= 1)
         nopen += __shfl_xor(nopen, off);
-    // the magnitude plane's last AGC_EXTRA samples move to the front (rtl_airband.cpp:643)
-    float* __restrict__ magrow = a.mag + static_cast<size_t>(row) * a.plane_stride;
-    if (a.last_chunk)
-        for (int v = lane; v < kAgcExtra; v += 64)
-            magrow[v] = magrow[a.nsteps + v];
+    // (the magnitude plane's last AGC_EXTRA samples, rtl_airband.cpp:643, are picked up where they are by the next call)
     if (lane != 0)
         return;
     const TpFinal f = a.fin[r];
@@ -1394,16 +1393,29 @@ __global__ __launch_bounds__(64) void k_tp_finish(const TpArgs a) {
     }
 }
 
-// head of the emitted audio = lookahead of the previous call (output.cpp:948); runs before any segment writes
+// seed of the core chain from the carried ChanState (first call, after a serial call or a restored checkpoint)
 __global__ void k_tp_prologue(const TpArgs a) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < a.nrows) {  // seed of the core chain
-        const ChanState& cs = a.st[a.rows[gid]];
-        TpCore t;
-        t.nf = cs.noise_floor, t.cap = cs.moving_avg_cap, t.c = cs.pre_capped, t.full = cs.pre_full;
-        a.core_carry[gid] = t;
-        a.full0[gid] = cs.pre_full;
-    }
+    if (gid >= a.nrows)
+        return;
+    const ChanState& cs = a.st[a.rows[gid]];
+    TpCore t;
+    t.nf = cs.noise_floor, t.cap = cs.moving_avg_cap, t.c = cs.pre_capped, t.full = cs.pre_full;
+    a.core_carry[gid] = t;
+}
+
+// pre_filter_.full_ at the start of the call = the chain state before this call's first core launch (seeded just above, or
+// left by the previous call's chain); k_tp_full reads it for its first lanes and as part of the sandwich's upper bound
+__global__ void k_tp_full0(const TpArgs a) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < a.nrows)
+        a.full0[gid] = a.core_carry[gid].full;
+}
+
+// head of the emitted audio = lookahead of the previous call (output.cpp:948); runs on the caller's stream after the
+// previous call's fades and before this call's
+__global__ void k_tp_audio_head(const TpArgs a) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= a.nrows * kAgcExtra)
         return;
     const int r = gid / kAgcExtra, v = gid - r * kAgcExtra;
@@ -1421,13 +1433,24 @@ __global__ void k_tp_prologue(const TpArgs a) {
             return e__;                                           \
     } while (0)
 
-hipError_t launch_tp_front(const TpArgs& a, hipStream_t s) {
+hipError_t launch_tp_front(const TpArgs& a, hipStream_t s, bool seed_chain) {
     if (a.nrows == 0 || a.step1 <= a.step0)
         return hipSuccess;
+    if (a.first_chunk && seed_chain)
+        TP_LAUNCH(k_tp_prologue, (a.nrows + 255) / 256, 256);
     if (a.first_chunk)
-        TP_LAUNCH(k_tp_prologue, (a.nrows * kAgcExtra + 255) / 256, 256);
+        TP_LAUNCH(k_tp_full0, (a.nrows + 255) / 256, 256);
     const int lanes1 = a.nrows * static_cast<int>((a.step1 - a.step0 + TP_L1 - 1) / TP_L1);
     TP_LAUNCH(k_tp_full, (lanes1 + 63) / 64, 64);
+    return hipSuccess;
+}
+
+// on the caller's stream when a call starts: after the previous call's fades (they write the lookahead), before any
+// segment pass of this call (its last segments write the next lookahead)
+hipError_t launch_tp_audio_head(const TpArgs& a, hipStream_t s) {
+    if (a.nrows == 0)
+        return hipSuccess;
+    TP_LAUNCH(k_tp_audio_head, (a.nrows * kAgcExtra + 255) / 256, 256);
     return hipSuccess;
 }
 

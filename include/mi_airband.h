@@ -169,6 +169,17 @@ int mi_demod_last_kernel_ms(mi_demod* h, float* channelize_ms, float* demod_ms);
  * sum over those launches (kernels of different chunks overlap on two streams, so the sums exceed the wall time).
  * Returns MI_ERR_INVALID past the last index: iterate from 0 until it fails.  *name is a static string. */
 int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms_total, int* launches);
+/* The same for the call before the last one (while its events have not been reused): lets a caller that keeps calls in
+ * flight read the timings of call k after it has enqueued call k+1, without draining the pipeline. */
+int mi_demod_kernel_time_prev(mi_demod* h, int index, const char** name, float* ms_total, int* launches);
+
+/* Options.  MI_OPT_EARLY_INPUT (default 0): the caller guarantees that the IQ bytes handed to
+ * mi_demod_process_device() are valid when the call is made (not merely in the order of `hip_stream`), e.g. a capture
+ * already resident in HBM or a ring filled by a copy engine the caller has synchronised with.  The library may then read
+ * them before the work queued earlier on `hip_stream` has finished, which lets stage 1 and the serial core chain of a call
+ * overlap the segment / fix passes of the previous call (time-parallel path).  Outputs still complete in stream order. */
+enum { MI_OPT_EARLY_INPUT = 1 };
+int mi_demod_set_option(mi_demod* h, int option, int value);
 
 /* ---- host-only views of the derived plan (no GPU needed; used by the CPU test-suite) ---- */
 typedef struct mi_plan mi_plan;

@@ -470,3 +470,41 @@ def test_time_parallel_pipeline_settings_do_not_change_a_bit(pkg, monkeypatch, c
     assert paths == [(1, 0), (1, 0)]
     assert_same(axc[0], oaxc, "axcindicate")
     assert_same(wo[0], owo, "audio")
+
+
+@pytest.mark.parametrize("calls", [[80, 80, 80], [48, 112, 16, 64], [160, 3, 77]])
+def test_consecutive_calls_overlap_with_early_input(pkg, monkeypatch, calls):
+    """MI_OPT_EARLY_INPUT: the capture is resident before the calls are made, so stage 1 and the core chain of call k+1 run
+    under the segment / fix passes of call k (two scratch sets, chain state handed over on the device).  All calls are
+    enqueued back to back without a host synchronisation in between; audio and flags must still be the oracle's.  A
+    3-batch call in the middle takes the serial kernel and breaks the chain hand-over once."""
+    import torch
+    monkeypatch.delenv("MI_AIRBAND_TP", raising=False)
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    nbat = sum(calls)
+    iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=3)
+    nb, owo, oaxc, _ = oracle_run(dev, chans, iq, nbat)
+    assert nb == nbat
+    pad = (iq.size + 255) // 256 * 256
+    d_iq = torch.zeros(pad, dtype=torch.uint8, device="cuda")
+    d_iq[:iq.size] = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    s = torch.cuda.current_stream().cuda_stream
+    d = pkg.Demod(dev, chans, nstreams=1, max_batches=max(calls))
+    d.set_option(pkg.OPT_EARLY_INPUT, 1)
+    outs, flags, done = [], [], 0
+    for k in calls:
+        pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+        wo = torch.empty((1, len(chans), k * WAVE_BATCH), dtype=torch.float32, device="cuda")
+        ax = torch.empty((1, len(chans), k), dtype=torch.uint8, device="cuda")
+        d.process_device(d_iq.data_ptr() + pos, pad - pos, k, wo.data_ptr(), ax.data_ptr(), hip_stream=s)
+        outs.append(wo)
+        flags.append(ax)
+        done += k
+    torch.cuda.synchronize()
+    wo = torch.cat(outs, dim=2).cpu().numpy()
+    ax = torch.cat(flags, dim=2).cpu().numpy()
+    d.close()
+    assert_same(ax[0], oaxc, "axcindicate")
+    assert_same(wo[0], owo, "audio")
