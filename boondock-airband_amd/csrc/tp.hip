@@ -27,10 +27,12 @@
 //                   (agcavgfast only where segment k reads it; otherwise it is passed through).  By
 //                   induction from the true state at step 0 an accepted segment started from the true state,
 //                   so its audio and E_k are the serial result.
-//  D   k_tp_fix     segments that were not accepted are re-run from E_{k-1}; a re-run lane keeps going
-//                   through the following segments until its state meets their recorded S.
-//      (C, D) run twice, then k_tp_fallback re-runs serially whatever is still unaccepted, so the result
-//      never depends on the speculation succeeding -- only the speed does.
+//  D   k_tp_fix     a lane per unaccepted segment walks on from E_{k-1} (states only) through the following segments
+//                   until its state meets their recorded S, leaving each member's true start state;
+//      k_tp_redo    re-runs every member from that state, side by side (audio, record).
+//      k_tp_settle  one wave per channel: scan again; while something is unaccepted, the same fix / redo by its own
+//                   lanes and another scan; finally a serial re-run from the first unaccepted segment.  The
+//                   result never depends on the speculation succeeding -- only the speed does.
 //  E   k_tp_finish  applies the AM close-edge fades (rtl_airband.cpp:564-568) that were deferred as events,
 //                   reduces axcindicate per WAVE_BATCH and writes the carried state for the next call.
 //
@@ -1095,10 +1097,9 @@ __device__ __forceinline__ TpFsm rec_fsm(const int* __restrict__ rec, const size
     return f;
 }
 
-__global__ __launch_bounds__(64) void k_tp_scan(const TpArgs a) {
-    const int r = blockIdx.x;
-    const int row = a.rows[r];
-    const int lane = threadIdx.x;
+// one wave per row; returns (wave-uniform) whether every segment of the chunk is accepted and the first that is not
+__device__ __forceinline__ bool scan_row(const TpArgs& a, const int r, const int row, const int lane, const int diag_slot, const bool diag_assign,
+                                         uint32_t& first_bad_out) {
     const int* __restrict__ rec = a.rec;
     const size_t st = a.rec_stride;
     const size_t base = static_cast<size_t>(r) * a.nseg;
@@ -1191,10 +1192,18 @@ __global__ __launch_bounds__(64) void k_tp_scan(const TpArgs a) {
         f.d_flappy = sum_flappy;
         a.fin[r] = f;
         if (a.diag) {  // unaccepted segments per scan round, summed over the chunks of the call
-            int* d = a.diag + r * 4 + (a.scan_round & 3);
-            *d = (a.first_chunk ? 0 : *d) + nbad;
+            int* d = a.diag + r * 4 + (diag_slot & 3);
+            *d = (diag_assign ? 0 : *d) + nbad;
         }
     }
+    first_bad_out = first_bad;
+    return all_ok;
+}
+
+__global__ __launch_bounds__(64) void k_tp_scan(const TpArgs a) {
+    const int r = blockIdx.x;
+    uint32_t fb;
+    (void)scan_row(a, r, a.rows[r], threadIdx.x, 0, a.first_chunk != 0, fb);
 }
 
 // =====================================================================================================
@@ -1261,19 +1270,9 @@ __global__ __launch_bounds__(64) void k_tp_fix(const TpArgs a) {
     rerun_chain<true>(a, r, row, p, k, TP_MAXCHAIN, true, false);
 }
 
-// every segment a chain of k_tp_fix passed through, from its true start state, audio and record included
-__global__ __launch_bounds__(64) void k_tp_redo(const TpArgs a) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nsc = static_cast<int>(a.seg1 - a.seg0);
-    if (gid >= a.nrows * nsc)
-        return;
-    const int r = gid / nsc;
-    const uint32_t k = a.seg0 + static_cast<uint32_t>(gid - r * nsc);
+// one segment from its true start state (tstart), audio and record included
+__device__ __forceinline__ void redo_segment(const TpArgs& a, const int r, const int row, const ChanParams& p, const uint32_t k) {
     const size_t base = static_cast<size_t>(r) * a.nseg;
-    if (a.need[base + k] != 2)
-        return;
-    const int row = a.rows[r];
-    const ChanParams p = a.cp[row % a.nch];
     const float* __restrict__ magrow = a.mag + static_cast<size_t>(row) * a.plane_stride;
     TpLane s;
     seg_reset(s);
@@ -1287,38 +1286,79 @@ __global__ __launch_bounds__(64) void k_tp_redo(const TpArgs a) {
     rec_store(a, base + k, S, s_agc, s);
 }
 
-// last resort: one lane per channel re-runs serially everything from the first unaccepted segment
-__global__ __launch_bounds__(64) void k_tp_fallback(const TpArgs a) {
-    const int r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= a.nrows)
-        return;
-    const TpFinal f = a.fin[r];
-    if (f.all_ok)
-        return;
-    const int row = a.rows[r];
-    const ChanParams p = a.cp[row % a.nch];
-    // tstart of first_bad was written from an accepted predecessor: it is the true state
-    rerun_chain<false>(a, r, row, p, f.first_bad, 0xffffffffu, false, true);
-}
-
-// =====================================================================================================
-// E: deferred fades, axcindicate, carried state
-// =====================================================================================================
-__global__ __launch_bounds__(64) void k_tp_fades(const TpArgs a) {
-    const int gid = blockIdx.x * 64 + threadIdx.x;
+// every segment a chain of k_tp_fix passed through, from its true start state, side by side
+__global__ __launch_bounds__(64) void k_tp_redo(const TpArgs a) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nsc = static_cast<int>(a.seg1 - a.seg0);
     if (gid >= a.nrows * nsc)
         return;
     const int r = gid / nsc;
     const uint32_t k = a.seg0 + static_cast<uint32_t>(gid - r * nsc);
+    const size_t base = static_cast<size_t>(r) * a.nseg;
+    if (a.need[base + k] != 2)
+        return;
     const int row = a.rows[r];
-    const size_t idx = static_cast<size_t>(r) * a.nseg + k;
+    const ChanParams p = a.cp[row % a.nch];
+    redo_segment(a, r, row, p, k);
+}
+
+// Everything the first scan / fix / redo round left open, settled by the row's own wave without further launches (a launch
+// costs tens of microseconds while the machine is busy with other passes, and the common case is "nothing left"): scan;
+// while segments are unaccepted the lanes take one chain head each (states only), then one chain member each (audio), and
+// scan again; after kSettleRounds the serial re-run from the first unaccepted segment.  What the lanes hand to each other
+// goes through global memory, so every phase ends with an agent-scope fence (drains the stores, invalidates the L1).
+constexpr int kSettleRounds = 6;
+__global__ __launch_bounds__(64) void k_tp_settle(const TpArgs a) {
+    const int r = blockIdx.x;
+    const int row = a.rows[r];
+    const int lane = threadIdx.x;
+    const ChanParams p = a.cp[row % a.nch];
+    const size_t base = static_cast<size_t>(r) * a.nseg;
+    if (lane == 0 && a.first_chunk && a.diag)
+        a.diag[r * 4 + 2] = a.diag[r * 4 + 3] = 0;
+    uint32_t first_bad = a.seg1;
+    bool ok = scan_row(a, r, row, lane, 1, a.first_chunk != 0, first_bad);
+    for (int round = 0; !ok && round < kSettleRounds; ++round) {
+        __threadfence();
+        __syncthreads();
+        for (uint32_t g0 = a.seg0; g0 < a.seg1; g0 += 64) {
+            const uint32_t k = g0 + lane;
+            if (k < a.seg1 && a.need[base + k] == 1)
+                rerun_chain<true>(a, r, row, p, k, TP_MAXCHAIN, true, false);
+        }
+        __threadfence();
+        __syncthreads();
+        for (uint32_t g0 = a.seg0; g0 < a.seg1; g0 += 64) {
+            const uint32_t k = g0 + lane;
+            if (k < a.seg1 && a.need[base + k] == 2)
+                redo_segment(a, r, row, p, k);
+        }
+        __threadfence();
+        __syncthreads();
+        ok = scan_row(a, r, row, lane, 2, false, first_bad);
+    }
+    if (!ok) {  // last resort: tstart of first_bad was written from an accepted predecessor, it is the true state
+        __threadfence();
+        __syncthreads();
+        if (lane == 0)
+            rerun_chain<false>(a, r, row, p, first_bad, 0xffffffffu, false, true);
+        __threadfence();
+        __syncthreads();
+        (void)scan_row(a, r, row, lane, 3, false, first_bad);
+    }
+}
+
+// =====================================================================================================
+// E: deferred fades, axcindicate, carried state
+// =====================================================================================================
+// the deferred AM close-edge fades of one segment (rtl_airband.cpp:564-568), applied once all audio of the chunk is final
+__device__ __forceinline__ void apply_fades(const TpArgs& a, const int row, const size_t idx) {
     const int nev = a.rec[18 * a.rec_stride + idx];
     float* __restrict__ wmain = a.wmain + static_cast<size_t>(row) * a.wmain_stride;
     float* __restrict__ carry = a.carry + static_cast<size_t>(row) * kAgcExtra;
     for (int e = 0; e < nev && e < TP_MAXEV; ++e) {
         const uint32_t i = static_cast<uint32_t>(a.rec[(19 + e) * a.rec_stride + idx]);
-        // rtl_airband.cpp:564-568: waveout[k] = waveout[k-1] * 0.94 for k = j-99 .. j-1, in virtual indices i+1 .. i+99
+        // waveout[k] = waveout[k-1] * 0.94 for k = j-99 .. j-1, in virtual indices i+1 .. i+99
         float v = (i < a.nsteps) ? wmain[i] : carry[i - a.nsteps];
         for (int kk = 1; kk < kAgcExtra; ++kk) {
             v = v * 0.94f;
@@ -1336,6 +1376,8 @@ __global__ __launch_bounds__(64) void k_tp_finish(const TpArgs a) {
     const int row = a.rows[r];
     const int lane = threadIdx.x;
     const size_t base = static_cast<size_t>(r) * a.nseg;
+    for (uint32_t k = a.seg0 + lane; k < a.seg1; k += 64)  // (events are >= 197 steps apart: the fades of a row never overlap)
+        apply_fades(a, row, base + k);
     // axcindicate per WAVE_BATCH from the segments' open masks
     int nopen = 0;
     for (uint32_t b = a.bat0 + lane; b < a.bat1; b += 64) {
@@ -1497,22 +1539,12 @@ hipError_t launch_tp_rest(const TpArgs& a_in, hipStream_t s, hipEvent_t* marks) 
     if (a.nrows == 0 || a.step1 <= a.step0)
         return hipSuccess;
     const int lanes = a.nrows * static_cast<int>(a.seg1 - a.seg0);
-    for (int round = 0; round < 2; ++round) {
-        a.scan_round = round;
-        TP_LAUNCH(k_tp_scan, a.nrows, 64);
-        if (round == 0)
-            TP_MARK(0);
-        TP_LAUNCH(k_tp_fix, (lanes + 63) / 64, 64);
-        TP_LAUNCH(k_tp_redo, (lanes + 3) / 4, 4);
-        if (round == 0)
-            TP_MARK(1);
-    }
-    a.scan_round = 2;
     TP_LAUNCH(k_tp_scan, a.nrows, 64);
-    TP_LAUNCH(k_tp_fallback, (a.nrows + 63) / 64, 64);
-    a.scan_round = 3;
-    TP_LAUNCH(k_tp_scan, a.nrows, 64);
-    TP_LAUNCH(k_tp_fades, (lanes + 63) / 64, 64);
+    TP_MARK(0);
+    TP_LAUNCH(k_tp_fix, (lanes + 63) / 64, 64);
+    TP_LAUNCH(k_tp_redo, (lanes + 3) / 4, 4);
+    TP_MARK(1);
+    TP_LAUNCH(k_tp_settle, a.nrows, 64);
     TP_LAUNCH(k_tp_finish, a.nrows, 64);
     TP_MARK(2);
     return hipSuccess;
