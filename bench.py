@@ -123,7 +123,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-    nbuf = 2 if gathering else 1
+    nbuf = 2  # consecutive steps write alternate audio buffers: the segment passes of step k+1 may run under the tail of step k
     d_wos = [torch.empty((nstreams, nch, nsteps), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
     d_wo = d_wos[0]
     d_axc = torch.empty((nstreams, nch, nbat), dtype=torch.uint8, device="cuda")

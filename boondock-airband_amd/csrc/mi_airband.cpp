@@ -122,7 +122,9 @@ struct mi_demod {
     unsigned* d_xmax[2] = {nullptr, nullptr};
     float *d_blk_fe[2] = {nullptr, nullptr}, *d_blk_fm[2] = {nullptr, nullptr}, *d_blk_x0[2] = {nullptr, nullptr}, *d_blk_xm[2] = {nullptr, nullptr};
     mi::TpCore* d_core[2] = {nullptr, nullptr};
-    int* d_rec = nullptr;
+    int* d_rec[2] = {nullptr, nullptr};  // per scratch set: the segment passes of the next call write theirs while this call's tail reads its own
+    const float* prev_out_lo = nullptr;  // audio buffer of the previous call (its tail may still be writing it)
+    const float* prev_out_hi = nullptr;
     int* d_tstart = nullptr;
     int* d_need = nullptr;
     mi::TpFinal* d_fin = nullptr;
@@ -235,6 +237,10 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         const int q = h->cur ^ 1;  // the scratch set of this call
         float* const planes = h->d_mag_set[q];
         const bool overlap = h->early_input && h->chain_live && !h->first_call;
+        const float* out_lo = d_wmain;
+        const float* out_hi = d_wmain + static_cast<size_t>(h->rows - 1) * wmain_stride + da.nsteps;
+        // segment passes may run under the previous call's tail only if they write a different audio buffer
+        const bool seg_early = overlap && (out_hi <= h->prev_out_lo || out_lo >= h->prev_out_hi);
         const uint32_t n = da.nsteps;
         const uint32_t units = n / mi::TP_CHUNK_UNIT;
         // Chunk sizes grow geometrically: a short first chunk gets the serial core chain going early (its stage 1 +
@@ -299,7 +305,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.core = h->d_core[q];
         ta.core_carry = h->d_core_carry;
         ta.full0 = h->d_full0;
-        ta.rec = h->d_rec;
+        ta.rec = h->d_rec[q];
         ta.rec_stride = static_cast<size_t>(h->rows) * h->tp_max_seg;
         ta.tstart = h->d_tstart;
         ta.need = h->d_need;
@@ -384,10 +390,27 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             HIP_TRY(mi::launch_tp_core(c, h->aux_stream));
             HIP_TRY(hipEventRecord(ev(i, 4), h->aux_stream));
             hipStream_t ss = h->seg_stream[i % mi_demod::kSegStreams];
-            HIP_TRY(hipStreamWaitEvent(ss, h->ev_head, 0));  // the final state and records of the previous call; the caller's order
+            // A segment pass needs core(i).  It also has to wait for the previous call (ev_head) where it touches what
+            // that call's tail still owns: the carried ChanState (the lanes of the first TP_W / TP_L + 1 segments start
+            // from it), the audio lookahead (written by the last segments) and the caller's audio buffer if it is the
+            // one the previous call wrote.
             HIP_TRY(hipStreamWaitEvent(ss, ev(i, 4), 0));
             HIP_TRY(hipEventRecord(ev(i, 5), ss));
-            HIP_TRY(mi::launch_tp_seg(c, ss));
+            const uint32_t head_end = std::min<uint32_t>(c.seg1, mi::TP_W / mi::TP_L + 1);
+            if (!seg_early || c.last_chunk) {
+                HIP_TRY(hipStreamWaitEvent(ss, h->ev_head, 0));
+                HIP_TRY(mi::launch_tp_seg(c, ss));
+            } else if (c.first_chunk && c.seg0 < head_end) {
+                mi::TpArgs body = c, head = c;
+                body.seg0 = head_end;
+                head.seg1 = head_end;
+                if (body.seg0 < body.seg1)
+                    HIP_TRY(mi::launch_tp_seg(body, ss));
+                HIP_TRY(hipStreamWaitEvent(ss, h->ev_head, 0));
+                HIP_TRY(mi::launch_tp_seg(head, ss));
+            } else {
+                HIP_TRY(mi::launch_tp_seg(c, ss));
+            }
             HIP_TRY(hipEventRecord(ev(i, 6), ss));
             HIP_TRY(hipStreamWaitEvent(s, ev(i, 6), 0));
             HIP_TRY(hipEventRecord(ev(i, 10), s));
@@ -399,6 +422,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         h->d_mag = planes;
         h->head_off = n;  // (first call: the planes hold AGC_EXTRA + n samples, the last AGC_EXTRA start at n as well)
         h->chain_live = true;
+        h->prev_out_lo = out_lo;
+        h->prev_out_hi = out_hi;
     } else if (h->plan.any_afc) {
         // AFC (rtl_airband.cpp:180-251): the bins stage 1 picks in batch b+1 depend on the squelch outcome of batch b, so
         // the batches are enqueued one at a time -- stage 1, channel loop, AFC::finalize -- with the bin table and the
@@ -476,7 +501,7 @@ void mi_demod_destroy(mi_demod* h) {
     (void)hipSetDevice(h->gpu);
     void* ptrs[] = {h->d_window, h->d_tw,   h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_mag_set[0], h->d_cplx, h->d_carry,
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc,
-                    h->d_rows,   h->d_xmax[0], h->d_xmax[1], h->d_blk_fe[0], h->d_blk_fm[0], h->d_blk_x0[0], h->d_blk_xm[0], h->d_blk_fe[1], h->d_blk_fm[1], h->d_blk_x0[1], h->d_blk_xm[1], h->d_core[0], h->d_core[1], h->d_mag_set[1], h->d_rec, h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_afc_spec};
+                    h->d_rows,   h->d_xmax[0], h->d_xmax[1], h->d_blk_fe[0], h->d_blk_fm[0], h->d_blk_x0[0], h->d_blk_xm[0], h->d_blk_fe[1], h->d_blk_fm[1], h->d_blk_x0[1], h->d_blk_xm[1], h->d_core[0], h->d_core[1], h->d_mag_set[1], h->d_rec[0], h->d_rec[1], h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_afc_spec};
     for (void* p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -625,7 +650,8 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
             TRY_OR_BAIL(dalloc(&h->d_blk_xm[q], rows * h->tp_max_blk));
             TRY_OR_BAIL(dalloc(&h->d_core[q], rows * (h->tp_max_seg + 1)));
         }
-        TRY_OR_BAIL(dalloc(&h->d_rec, static_cast<size_t>(mi::TP_NREC) * rows * h->tp_max_seg));
+        for (int q = 0; q < 2; ++q)
+            TRY_OR_BAIL(dalloc(&h->d_rec[q], static_cast<size_t>(mi::TP_NREC) * rows * h->tp_max_seg));
         TRY_OR_BAIL(dalloc(&h->d_tstart, rows * h->tp_max_seg * 8));
         TRY_OR_BAIL(dalloc(&h->d_need, rows * h->tp_max_seg));
         TRY_OR_BAIL(dalloc(&h->d_fin, rows));
