@@ -499,6 +499,7 @@ void mi_demod_destroy(mi_demod* h) {
     if (!h)
         return;
     (void)hipSetDevice(h->gpu);
+    (void)hipDeviceSynchronize();  // calls may still be in flight on the handle's own streams
     void* ptrs[] = {h->d_window, h->d_tw,   h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_mag_set[0], h->d_cplx, h->d_carry,
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc,
                     h->d_rows,   h->d_xmax[0], h->d_xmax[1], h->d_blk_fe[0], h->d_blk_fm[0], h->d_blk_x0[0], h->d_blk_xm[0], h->d_blk_fe[1], h->d_blk_fm[1], h->d_blk_x0[1], h->d_blk_xm[1], h->d_core[0], h->d_core[1], h->d_mag_set[1], h->d_rec[0], h->d_rec[1], h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_afc_spec};
