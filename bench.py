@@ -154,7 +154,12 @@ def main():
         b = nstep[0] % nbuf
         nstep[0] += 1
         if pending[b] is not None:
-            pending[b].wait()  # the stream waits for the gather that still reads this buffer
+            # The gather of two steps ago still reads this buffer.  With MI_OPT_EARLY_INPUT the library may write a call's
+            # audio before the stream reaches the call, so a stream-side wait is not enough: the host waits (the gather
+            # started when that step finished, a whole step ago, so this normally returns at once).
+            while not pending[b].is_completed():
+                time.sleep(0)
+            pending[b].wait()
             pending[b] = None
         h.process_device(base, nbytes - AGC_EXTRA * hop, nbat, d_wos[b].data_ptr(), d_axc.data_ptr(), hip_stream=stream.cuda_stream)
         if gathering:

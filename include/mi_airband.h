@@ -177,7 +177,9 @@ int mi_demod_kernel_time_prev(mi_demod* h, int index, const char** name, float* 
  * mi_demod_process_device() are valid when the call is made (not merely in the order of `hip_stream`), e.g. a capture
  * already resident in HBM or a ring filled by a copy engine the caller has synchronised with.  The library may then read
  * them before the work queued earlier on `hip_stream` has finished, which lets stage 1 and the serial core chain of a call
- * overlap the segment / fix passes of the previous call (time-parallel path).  Outputs still complete in stream order. */
+ * overlap the segment / fix passes of the previous call (time-parallel path).  Outputs still complete in stream order.
+ * The audio buffer of a call must then also be free when the call is made (no reader of an earlier result still pending on
+ * another stream): when it is not the buffer of the previous call, the segment passes may write it early. */
 enum { MI_OPT_EARLY_INPUT = 1 };
 int mi_demod_set_option(mi_demod* h, int option, int value);
 
