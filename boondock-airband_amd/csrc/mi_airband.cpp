@@ -247,7 +247,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         // aggregates are all that precedes it), later chunks are long because every wide pass has a fixed latency per
         // launch.  MI_AIRBAND_TP_CHUNKS / MI_AIRBAND_TP_RATIO override the measured defaults.
         int want = 3;
-        double ratio = 1.5;
+        double ratio = overlap ? 1.0 : 1.5;  // (when calls overlap the chain is already running: equal chunks measured best)
         if (const char* e = std::getenv("MI_AIRBAND_TP_CHUNKS"))
             want = std::max(1, std::atoi(e));
         if (const char* e = std::getenv("MI_AIRBAND_TP_RATIO"))
