@@ -145,7 +145,11 @@ struct TpArgs {
     float *blk_fe, *blk_fm, *blk_x0, *blk_xm;  // [nrows][nblk]
     TpCore* core;                              // [nrows][nseg+1]
     TpCore* core_carry;                        // [nrows] chain state handed from one chunk's core kernel to the next
-    float* full0;                              // [nrows] pre_filter_.full_ at the start of the call
+    float* full0;                              // [nrows] pre_filter_.full_ at the start of the call (only when the chain was seeded)
+    float* fullbound;                          // [nrows] an upper bound of pre_filter_.full_ at the start of the call
+    const float* prev_mag;                     // planes of the previous call (its last TP_W1 steps warm up this call's first lanes), or null
+    uint32_t prev_n;                           // steps of the previous call
+    const unsigned* xmax_prev;                 // xmax of the previous call
     int* rec;                                  // [TP_NREC][rec_stride]
     size_t rec_stride;
     int* tstart;                               // [nrows*nseg][8]

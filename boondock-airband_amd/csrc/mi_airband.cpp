@@ -68,30 +68,32 @@ struct mi_demod {
     bool first_call = true;  // waveend starts at 0: the first batch needs AGC_EXTRA more windows (config.cpp:808)
     size_t plane_stride = 0;
     hipStream_t own_stream = nullptr;
-    // The time-parallel path keeps two sets of its per-call scratch (magnitude planes, block aggregates, core snapshots,
-    // timing events) and alternates between them: stage 1, the aggregates and the core chain of the next call never touch
-    // what the segment and fix passes of the previous call still read, so consecutive calls overlap (see enqueue()).
+    // The time-parallel path keeps kSets sets of its per-call scratch (magnitude planes, block aggregates, core snapshots,
+    // segment records, timing events) and cycles through them: stage 1, the aggregates, the core chain and the segment
+    // passes of a call never touch what the tails of the two calls before it still read, so calls overlap (see enqueue()).
     // `cur` is the set of the last call; the serial path stays on it.
     int cur = 0;
-    hipEvent_t ev[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    static constexpr int kSets = 3;  // a call writes the set of the call three back: by then that call has long finished
+    hipEvent_t ev[kSets][3] = {};
     static constexpr int kMaxChunks = 64, kEvPerChunk = 12, kSegStreams = 1;
-    std::vector<hipEvent_t> chunk_ev[2];  // per chunk: stage1 begin/end, full end, core begin/end, seg begin/end, scan0/fix0/finish ends, rest begin
+    std::vector<hipEvent_t> chunk_ev[kSets];  // per chunk: stage1 begin/end, full end, core begin/end, seg begin/end, scan0/fix0/finish ends, rest begin
     hipStream_t aux_stream = nullptr;    // carries the serial core chain of the time-parallel path
     hipStream_t front_stream = nullptr;  // stage 1 + aggregates of the time-parallel path
     hipEvent_t ev_entry = nullptr;       // recorded on the caller's stream when a call starts
     hipEvent_t ev_head = nullptr;        // ... and after the audio head of the call has been written
-    float* d_mag_set[2] = {nullptr, nullptr};  // d_mag aliases d_mag_set[cur]
+    float* d_mag_set[kSets] = {};  // d_mag aliases d_mag_set[cur]
     uint32_t head_off = 0;     // plane index where the AGC_EXTRA carried samples of every row live (0 after a serial call)
     bool early_input = false;  // MI_OPT_EARLY_INPUT: the IQ of a call is valid when the call is made
     bool chain_live = false;   // d_core_carry holds the chain state at the end of the previous call (it was time-parallel)
     hipStream_t seg_stream[kSegStreams] = {nullptr};  // the speculative segment passes (need core(i) only)
-    int tp_chunks[2] = {0, 0};
+    int tp_chunks[kSets] = {};
     mi::TpCore* d_core_carry = nullptr;
     float* d_full0 = nullptr;
+    float* d_fullbound = nullptr;
     float* d_afc_spec = nullptr;  // [nstreams][fft_size] squared spectrum of the last window of a batch (AFC handles only)
-    uint64_t set_seq[2] = {0, 0};  // call number that last used each event set (0 = never)
+    uint64_t set_seq[kSets] = {};  // call number that last used each event set (0 = never)
     uint64_t call_seq = 0;
-    int set_path[2] = {0, 0};
+    int set_path[kSets] = {};
     // device memory
     float* d_window = nullptr;
     float* d_tw = nullptr;
@@ -119,17 +121,17 @@ struct mi_demod {
     bool tp_eligible = false;
     int last_path = 0;  // 0 = serial kernel, 1 = time-parallel
     int* d_rows = nullptr;
-    unsigned* d_xmax[2] = {nullptr, nullptr};
-    float *d_blk_fe[2] = {nullptr, nullptr}, *d_blk_fm[2] = {nullptr, nullptr}, *d_blk_x0[2] = {nullptr, nullptr}, *d_blk_xm[2] = {nullptr, nullptr};
-    mi::TpCore* d_core[2] = {nullptr, nullptr};
-    int* d_rec[2] = {nullptr, nullptr};  // per scratch set: the segment passes of the next call write theirs while this call's tail reads its own
+    unsigned* d_xmax[kSets] = {};
+    float *d_blk_fe[kSets] = {}, *d_blk_fm[kSets] = {}, *d_blk_x0[kSets] = {}, *d_blk_xm[kSets] = {};
+    mi::TpCore* d_core[kSets] = {};
+    int* d_rec[kSets] = {};  // per scratch set: the segment passes of the next call write theirs while this call's tail reads its own
     const float* prev_out_lo = nullptr;  // audio buffer of the previous call (its tail may still be writing it)
     const float* prev_out_hi = nullptr;
     int* d_tstart = nullptr;
     int* d_need = nullptr;
     mi::TpFinal* d_fin = nullptr;
     int* d_diag = nullptr;
-    uint32_t last_nseg[2] = {0, 0};
+    uint32_t last_nseg[kSets] = {};
     size_t tp_max_blk = 0, tp_max_seg = 0;
 };
 
@@ -234,13 +236,14 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         //   caller's     : audio head, then scan / fix / redo / finish of chunk i after seg(i) and the chain of chunk i-1
         // With MI_OPT_EARLY_INPUT the front and aux streams do not wait for the caller's stream, i.e. for the segment
         // and fix passes of the previous call: consecutive calls overlap and the core chain runs back to back.
-        const int q = h->cur ^ 1;  // the scratch set of this call
+        const int q = (h->cur + 1) % mi_demod::kSets;  // the scratch set of this call
         float* const planes = h->d_mag_set[q];
         const bool overlap = h->early_input && h->chain_live && !h->first_call;
         const float* out_lo = d_wmain;
         const float* out_hi = d_wmain + static_cast<size_t>(h->rows - 1) * wmain_stride + da.nsteps;
         // segment passes may run under the previous call's tail only if they write a different audio buffer
         const bool seg_early = overlap && (out_hi <= h->prev_out_lo || out_lo >= h->prev_out_hi);
+        const int before_prev = (h->cur + mi_demod::kSets - 1) % mi_demod::kSets;
         const uint32_t n = da.nsteps;
         const uint32_t units = n / mi::TP_CHUNK_UNIT;
         // Chunk sizes grow geometrically: a short first chunk gets the serial core chain going early (its stage 1 +
@@ -305,6 +308,10 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.core = h->d_core[q];
         ta.core_carry = h->d_core_carry;
         ta.full0 = h->d_full0;
+        ta.fullbound = h->d_fullbound;
+        ta.prev_mag = overlap ? h->d_mag : nullptr;  // (still the previous call's planes here)
+        ta.prev_n = h->head_off;
+        ta.xmax_prev = h->d_xmax[h->cur];
         ta.rec = h->d_rec[q];
         ta.rec_stride = static_cast<size_t>(h->rows) * h->tp_max_seg;
         ta.tstart = h->d_tstart;
@@ -349,36 +356,17 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         if (!overlap)
             HIP_TRY(hipStreamWaitEvent(fs, h->ev_entry, 0));  // stage 1 honours the caller's stream order
         else if (h->set_seq[q])
-            HIP_TRY(hipStreamWaitEvent(fs, h->ev[q][2], 0));  // the call before the previous one has left this scratch set
+            HIP_TRY(hipStreamWaitEvent(fs, h->ev[q][2], 0));  // the call that used this scratch set last (three back) has left it
         // the carried samples of the previous call (wherever they are) become the head of this call's planes
         HIP_TRY(mi::launch_move_head(planes, h->d_mag + h->head_off, h->plane_stride, h->rows, fs));
         HIP_TRY(hipMemsetAsync(h->d_xmax[q], 0, static_cast<size_t>(h->rows) * sizeof(unsigned), fs));
-        // Stage 1 + aggregates of every chunk first: nothing else feeds them.  When calls overlap, k_tp_full of chunk 0 has
-        // to wait for the end of the previous call's chain (it starts from its full_): stage 1 runs one chunk ahead of the
-        // aggregates so that the wait does not hold up the stage 1 the chain needs next.
-        const int lead = overlap ? 1 : 0;
-        auto do_stage1 = [&](int i) -> int {
+        // Stage 1 + aggregates of every chunk first: nothing else feeds them (when calls overlap, k_tp_full warms its first
+        // lanes up on the previous call's planes, so not even the chain state of that call).
+        for (int i = 0; i < C; ++i) {
             const mi::TpArgs c = chunk(i);
             HIP_TRY(hipEventRecord(ev(i, 0), fs));
             HIP_TRY(stage1(c));
             HIP_TRY(hipEventRecord(ev(i, 1), fs));
-            return MI_OK;
-        };
-        int staged = 0;  // chunks whose stage 1 has been queued
-        for (; staged < std::min(lead + 1, C); ++staged) {
-            int rc = do_stage1(staged);
-            if (rc != MI_OK)
-                return rc;
-        }
-        for (int i = 0; i < C; ++i) {
-            if (i >= staged) {
-                int rc = do_stage1(staged++);
-                if (rc != MI_OK)
-                    return rc;
-            }
-            const mi::TpArgs c = chunk(i);
-            if (i == 0 && overlap)  // the chain state at the end of the previous call
-                HIP_TRY(hipStreamWaitEvent(fs, h->chunk_ev[h->cur][static_cast<size_t>(h->tp_chunks[h->cur] - 1) * mi_demod::kEvPerChunk + 4], 0));
             HIP_TRY(hipEventRecord(ev(i, 11), fs));
             HIP_TRY(mi::launch_tp_front(c, fs, /*seed_chain=*/!overlap));
             HIP_TRY(hipEventRecord(ev(i, 2), fs));
@@ -395,6 +383,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             // from it), the audio lookahead (written by the last segments) and the caller's audio buffer if it is the
             // one the previous call wrote.
             HIP_TRY(hipStreamWaitEvent(ss, ev(i, 4), 0));
+            if (seg_early && h->set_seq[before_prev])  // the call before the previous one is complete (two audio buffers alternate)
+                HIP_TRY(hipStreamWaitEvent(ss, h->ev[before_prev][2], 0));
             HIP_TRY(hipEventRecord(ev(i, 5), ss));
             const uint32_t head_end = std::min<uint32_t>(c.seg1, mi::TP_W / mi::TP_L + 1);
             if (!seg_early || c.last_chunk) {
@@ -500,15 +490,21 @@ void mi_demod_destroy(mi_demod* h) {
         return;
     (void)hipSetDevice(h->gpu);
     (void)hipDeviceSynchronize();  // calls may still be in flight on the handle's own streams
-    void* ptrs[] = {h->d_window, h->d_tw,   h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_mag_set[0], h->d_cplx, h->d_carry,
+    void* ptrs[] = {h->d_window, h->d_tw,   h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx, h->d_carry,
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc,
-                    h->d_rows,   h->d_xmax[0], h->d_xmax[1], h->d_blk_fe[0], h->d_blk_fm[0], h->d_blk_x0[0], h->d_blk_xm[0], h->d_blk_fe[1], h->d_blk_fm[1], h->d_blk_x0[1], h->d_blk_xm[1], h->d_core[0], h->d_core[1], h->d_mag_set[1], h->d_rec[0], h->d_rec[1], h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_afc_spec};
+                    h->d_rows,   h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_fullbound, h->d_afc_spec};
     for (void* p : ptrs)
         if (p)
             (void)hipFree(p);
+    for (int q = 0; q < mi_demod::kSets; ++q) {
+        void* sets[] = {h->d_mag_set[q], h->d_xmax[q], h->d_blk_fe[q], h->d_blk_fm[q], h->d_blk_x0[q], h->d_blk_xm[q], h->d_core[q], h->d_rec[q]};
+        for (void* p : sets)
+            if (p)
+                (void)hipFree(p);
+    }
     if (h->h_pin)
         (void)hipHostFree(h->h_pin);
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < mi_demod::kSets; ++q) {
         for (hipEvent_t e : h->ev[q])
             if (e)
                 (void)hipEventDestroy(e);
@@ -641,9 +637,11 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
             ident[i] = static_cast<int>(i);
         TRY_OR_BAIL(dalloc(&h->d_rows, rows));
         TRY_OR_BAIL(hipMemcpy(h->d_rows, ident.data(), rows * sizeof(int), hipMemcpyHostToDevice));
-        TRY_OR_BAIL(dalloc(&h->d_mag_set[1], rows * h->plane_stride));
-        TRY_OR_BAIL(hipMemset(h->d_mag_set[1], 0, rows * h->plane_stride * 4));
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 1; q < mi_demod::kSets; ++q) {
+            TRY_OR_BAIL(dalloc(&h->d_mag_set[q], rows * h->plane_stride));
+            TRY_OR_BAIL(hipMemset(h->d_mag_set[q], 0, rows * h->plane_stride * 4));
+        }
+        for (int q = 0; q < mi_demod::kSets; ++q) {
             TRY_OR_BAIL(dalloc(&h->d_xmax[q], rows));
             TRY_OR_BAIL(dalloc(&h->d_blk_fe[q], rows * h->tp_max_blk));
             TRY_OR_BAIL(dalloc(&h->d_blk_fm[q], rows * h->tp_max_blk));
@@ -651,7 +649,7 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
             TRY_OR_BAIL(dalloc(&h->d_blk_xm[q], rows * h->tp_max_blk));
             TRY_OR_BAIL(dalloc(&h->d_core[q], rows * (h->tp_max_seg + 1)));
         }
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < mi_demod::kSets; ++q)
             TRY_OR_BAIL(dalloc(&h->d_rec[q], static_cast<size_t>(mi::TP_NREC) * rows * h->tp_max_seg));
         TRY_OR_BAIL(dalloc(&h->d_tstart, rows * h->tp_max_seg * 8));
         TRY_OR_BAIL(dalloc(&h->d_need, rows * h->tp_max_seg));
@@ -659,6 +657,8 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
         TRY_OR_BAIL(hipMemset(h->d_fin, 0, rows * sizeof(mi::TpFinal)));
         TRY_OR_BAIL(dalloc(&h->d_core_carry, rows));
         TRY_OR_BAIL(dalloc(&h->d_full0, rows));
+        TRY_OR_BAIL(dalloc(&h->d_fullbound, rows));
+        TRY_OR_BAIL(hipMemset(h->d_fullbound, 0, rows * sizeof(float)));
         TRY_OR_BAIL(dalloc(&h->d_diag, rows * 8));
         TRY_OR_BAIL(hipMemset(h->d_diag, 0, rows * 8 * sizeof(int)));
     }
@@ -903,7 +903,7 @@ int mi_demod_read_planes(mi_demod* h, int stream, int ch, int first, int count, 
 static int kernel_time_of(mi_demod* h, int age, int index, const char** name, float* ms_total, int* launches) {
     if (!h || index < 0 || age < 0 || age > 1)
         return fail(MI_ERR_INVALID, "bad argument");
-    const int q = h->cur ^ age;
+    const int q = (h->cur + mi_demod::kSets - age) % mi_demod::kSets;
     if (!h->set_seq[q] || (age == 1 && h->set_seq[q] + 1 != h->set_seq[h->cur]))
         return fail(MI_ERR_INVALID, "that call has not been timed (or its events were reused)");
     HIP_TRY(hipSetDevice(h->gpu));

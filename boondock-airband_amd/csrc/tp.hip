@@ -90,13 +90,26 @@ __global__ __launch_bounds__(64) void k_tp_full(const TpArgs a) {
     const uint32_t t1 = min(t0 + TP_L1, a.step1);
     const uint32_t tw = t0 > TP_W1 ? t0 - TP_W1 : 0;
     float lo, hi;
-    if (tw == 0) {
+    if (tw == 0 && !a.prev_mag) {
         lo = hi = a.full0[r];  // the true value at the call start: exact from the first step
     } else {
         lo = 0.0f;
-        // any earlier value of full_ is bounded by its value at the start of the call and the largest sample so far
-        const float mx = fmaxf(__uint_as_float(a.xmax[row]), a.full0[r]);
+        // any earlier value of full_ is bounded by (a bound of) its value at the start of the call and the largest sample so far
+        const float mx = fmaxf(__uint_as_float(a.xmax[row]), a.fullbound[r]);
         hi = mx * 1.0001f + 1e-30f;
+        if (tw == 0 && t0 < TP_W1) {
+            // The warm-up reaches back into the previous call: its last samples are still in its planes.  Nothing here
+            // depends on the chain state of that call, so this kernel never waits for its core launches.
+            const uint32_t nprev = TP_W1 - t0;  // a multiple of 16, like prev_n
+            const float* __restrict__ xp = a.prev_mag + static_cast<size_t>(row) * a.plane_stride + kAgcExtra + (a.prev_n - nprev);
+            for (uint32_t i = 0; i < nprev; i += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(xp + i);
+                lo = ema99(lo, v.x), hi = ema99(hi, v.x);
+                lo = ema99(lo, v.y), hi = ema99(hi, v.y);
+                lo = ema99(lo, v.z), hi = ema99(hi, v.z);
+                lo = ema99(lo, v.w), hi = ema99(hi, v.w);
+            }
+        }
     }
     for (uint32_t i = tw; i < t0; i += 4) {  // warm-up (tw and t0 are multiples of 16)
         const float4 v = *reinterpret_cast<const float4*>(x + i);
@@ -1450,8 +1463,19 @@ __global__ void k_tp_prologue(const TpArgs a) {
 // left by the previous call's chain); k_tp_full reads it for its first lanes and as part of the sandwich's upper bound
 __global__ void k_tp_full0(const TpArgs a) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < a.nrows) {
+        const float f = a.core_carry[gid].full;
+        a.full0[gid] = f;
+        a.fullbound[gid] = f;
+    }
+}
+
+// When calls overlap the chain state of the previous call is not known yet: full_ at its end is bounded by the bound at its
+// start and the largest sample it saw.
+__global__ void k_tp_fullbound(const TpArgs a) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < a.nrows)
-        a.full0[gid] = a.core_carry[gid].full;
+        a.fullbound[gid] = fmaxf(a.fullbound[gid], __uint_as_float(a.xmax_prev[a.rows[gid]]));
 }
 
 // head of the emitted audio = lookahead of the previous call (output.cpp:948); runs on the caller's stream after the
@@ -1478,10 +1502,12 @@ __global__ void k_tp_audio_head(const TpArgs a) {
 hipError_t launch_tp_front(const TpArgs& a, hipStream_t s, bool seed_chain) {
     if (a.nrows == 0 || a.step1 <= a.step0)
         return hipSuccess;
-    if (a.first_chunk && seed_chain)
+    if (a.first_chunk && seed_chain) {
         TP_LAUNCH(k_tp_prologue, (a.nrows + 255) / 256, 256);
-    if (a.first_chunk)
         TP_LAUNCH(k_tp_full0, (a.nrows + 255) / 256, 256);
+    } else if (a.first_chunk) {
+        TP_LAUNCH(k_tp_fullbound, (a.nrows + 255) / 256, 256);
+    }
     const int lanes1 = a.nrows * static_cast<int>((a.step1 - a.step0 + TP_L1 - 1) / TP_L1);
     TP_LAUNCH(k_tp_full, (lanes1 + 63) / 64, 64);
     return hipSuccess;
