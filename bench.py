@@ -142,7 +142,7 @@ def main():
     kms = {}  # kernel name -> [total ms over the timed steps, launches]
 
     nstep = [0]
-    prev_timed = [False]
+    timed_hist = [False, False]  # was the step one / two steps ago a timed one
 
     def add_times(times):
         for name, ms, launches in times:  # HIP events around the launches, on the launch streams
@@ -164,10 +164,10 @@ def main():
         h.process_device(base, nbytes - AGC_EXTRA * hop, nbat, d_wos[b].data_ptr(), d_axc.data_ptr(), hip_stream=stream.cuda_stream)
         if gathering:
             pending[b] = dist.gather(d_wos[b], gather_lists[b], dst=0, async_op=True)
-        # the timings of a step are read one step later, so that reading them does not drain the pipeline
-        if prev_timed[0]:
-            add_times(h.kernel_times(prev=True))
-        prev_timed[0] = timed
+        # the timings of a step are read two steps later, so that reading them does not drain the pipeline
+        if timed_hist[1]:
+            add_times(h.kernel_times(age=2))
+        timed_hist[1], timed_hist[0] = timed_hist[0], timed
 
     for _ in range(args.warmup):
         step(False)
@@ -182,8 +182,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
-    add_times(h.kernel_times())  # (synchronises with the end of the last step)
-    prev_timed[0] = False
+    if timed_hist[1]:
+        add_times(h.kernel_times(age=1))
+    if timed_hist[0]:
+        add_times(h.kernel_times())  # (synchronises with the end of the last step)
+    timed_hist[0] = timed_hist[1] = False
     for b in range(nbuf):  # every gather of the timed steps completes inside the timed region
         if pending[b] is not None:
             pending[b].wait()

@@ -119,7 +119,7 @@ def lib():
         L.mi_demod_set_state.argtypes = [vp, vp, sz]
         L.mi_demod_last_path.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mi_demod_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int)]
-        L.mi_demod_kernel_time_prev.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.mi_demod_kernel_time_prev.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.mi_demod_set_option.argtypes = [vp, C.c_int, C.c_int]
         L.mi_demod_tp_debug.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_int)]
         L.mi_demod_read_planes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -304,15 +304,14 @@ class Demod:
     def set_option(self, option, value):
         _check(lib().mi_demod_set_option(self._h, option, value))
 
-    def kernel_times(self, prev=False):
-        """[(kernel name, total ms, launches)] of the last call -- or, with prev, of the call before it -- from HIP events
+    def kernel_times(self, age=0):
+        """[(kernel name, total ms, launches)] of the last call (age 0) or of the call `age` calls before it, from HIP events
         on the launch streams."""
         out = []
         i = 0
-        fn = lib().mi_demod_kernel_time_prev if prev else lib().mi_demod_kernel_time
         while True:
             name, ms, n = C.c_char_p(), C.c_float(0), C.c_int(0)
-            if fn(self._h, i, C.byref(name), C.byref(ms), C.byref(n)) != MI_OK:
+            if lib().mi_demod_kernel_time_prev(self._h, age, i, C.byref(name), C.byref(ms), C.byref(n)) != MI_OK:
                 break
             out.append((name.value.decode(), ms.value, n.value))
             i += 1

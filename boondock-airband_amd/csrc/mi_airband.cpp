@@ -901,10 +901,10 @@ int mi_demod_read_planes(mi_demod* h, int stream, int ch, int first, int count, 
 
 // timing of the last call (age 0) or of the call before it (age 1, only while its event set has not been reused)
 static int kernel_time_of(mi_demod* h, int age, int index, const char** name, float* ms_total, int* launches) {
-    if (!h || index < 0 || age < 0 || age > 1)
+    if (!h || index < 0 || age < 0 || age >= mi_demod::kSets)
         return fail(MI_ERR_INVALID, "bad argument");
     const int q = (h->cur + mi_demod::kSets - age) % mi_demod::kSets;
-    if (!h->set_seq[q] || (age == 1 && h->set_seq[q] + 1 != h->set_seq[h->cur]))
+    if (!h->set_seq[q] || h->set_seq[q] + static_cast<uint64_t>(age) != h->set_seq[h->cur])
         return fail(MI_ERR_INVALID, "that call has not been timed (or its events were reused)");
     HIP_TRY(hipSetDevice(h->gpu));
     hipEvent_t* evq = h->ev[q];
@@ -947,8 +947,8 @@ int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms_to
     return kernel_time_of(h, 0, index, name, ms_total, launches);
 }
 
-int mi_demod_kernel_time_prev(mi_demod* h, int index, const char** name, float* ms_total, int* launches) {
-    return kernel_time_of(h, 1, index, name, ms_total, launches);
+int mi_demod_kernel_time_prev(mi_demod* h, int age, int index, const char** name, float* ms_total, int* launches) {
+    return kernel_time_of(h, age, index, name, ms_total, launches);
 }
 
 int mi_demod_last_kernel_ms(mi_demod* h, float* channelize_ms, float* demod_ms) {
