@@ -508,3 +508,56 @@ def test_consecutive_calls_overlap_with_early_input(pkg, monkeypatch, calls):
     d.close()
     assert_same(ax[0], oaxc, "axcindicate")
     assert_same(wo[0], owo, "audio")
+
+
+def test_checkpoint_between_overlapping_calls_and_timing_ages(pkg, monkeypatch):
+    """A checkpoint taken while calls are in flight (it drains them), restored into a fresh handle, continues bit for bit; the
+    per-kernel timings of the last three calls stay readable by age."""
+    import torch
+    monkeypatch.delenv("MI_AIRBAND_TP", raising=False)
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    calls = [40, 40, 40, 40]
+    nbat = sum(calls)
+    iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=3)
+    nb, owo, oaxc, _ = oracle_run(dev, chans, iq, nbat)
+    pad = (iq.size + 255) // 256 * 256
+    d_iq = torch.zeros(pad, dtype=torch.uint8, device="cuda")
+    d_iq[:iq.size] = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(d, first, n):
+        outs = []
+        done = first
+        for k in calls[first:first + n]:
+            b = sum(calls[:done])
+            pos = 0 if b == 0 else (b * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+            wo = torch.empty((1, len(chans), k * WAVE_BATCH), dtype=torch.float32, device="cuda")
+            ax = torch.empty((1, len(chans), k), dtype=torch.uint8, device="cuda")
+            d.process_device(d_iq.data_ptr() + pos, pad - pos, k, wo.data_ptr(), ax.data_ptr(), hip_stream=s)
+            outs.append((wo, ax))
+            done += 1
+        return outs
+
+    a = pkg.Demod(dev, chans, nstreams=1, max_batches=max(calls))
+    a.set_option(pkg.OPT_EARLY_INPUT, 1)
+    first = run(a, 0, 3)
+    ages = [dict((n, ms) for n, ms, _ in a.kernel_times(age=g)) for g in range(3)]
+    assert all("k_tp_core" in t and t["k_tp_core"] > 0 for t in ages)
+    blob = a.get_state()  # (synchronises the device)
+    rest_a = run(a, 3, 1)
+    torch.cuda.synchronize()
+    a.close()
+    b = pkg.Demod(dev, chans, nstreams=1, max_batches=max(calls))
+    b.set_option(pkg.OPT_EARLY_INPUT, 1)
+    b.set_state(blob)
+    rest_b = run(b, 3, 1)
+    torch.cuda.synchronize()
+    b.close()
+    wo = torch.cat([x[0] for x in first + rest_a], dim=2).cpu().numpy()
+    ax = torch.cat([x[1] for x in first + rest_a], dim=2).cpu().numpy()
+    assert_same(ax[0], oaxc, "axcindicate")
+    assert_same(wo[0], owo, "audio")
+    assert_same(rest_b[0][0].cpu().numpy(), rest_a[0][0].cpu().numpy(), "audio after restoring the checkpoint")
+    assert_same(rest_b[0][1].cpu().numpy(), rest_a[0][1].cpu().numpy(), "flags after restoring the checkpoint")
