@@ -220,7 +220,7 @@ def main():
         }
         # A long call is processed in chunks: a kernel runs `launches_per_step` times per step, each launch over
         # 1/launches_per_step of the samples.  ms / bytes below are PER LAUNCH (what rocprofv3's average shows);
-        # ms_per_step is their sum over the step (kernels of different chunks overlap on two streams).
+        # ms_per_step is their sum over the step (kernels of different chunks and steps overlap on several streams).
         kernels = {}
         for name, (tot, launches) in kms.items():
             per_step = launches / args.steps

@@ -156,7 +156,6 @@ struct TpArgs {
     int* need;                                 // [nrows*nseg]
     TpFinal* fin;                              // [nrows]
     int* diag;                                 // [nrows][4] segments not accepted in scan 0..3, then [nrows][4] core-chain block counts
-    int scan_round;
 };
 constexpr uint32_t TP_CHUNK_UNIT = 64000;  // lcm(TP_L = 512, WAVE_BATCH = 2000)
 

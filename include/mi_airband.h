@@ -166,7 +166,7 @@ int mi_demod_last_kernel_ms(mi_demod* h, float* channelize_ms, float* demod_ms);
  * index 0 is the channelize kernel; then "k_demod" (serial path) or the kernels of the time-parallel path
  * ("k_tp_full", "k_tp_core", "k_tp_seg", "k_tp_scan#0", "k_tp_fix#0", "k_tp_rest" = the remaining small launches).
  * The time-parallel path runs a long call in chunks, so a kernel is launched *launches times; *ms_total is the
- * sum over those launches (kernels of different chunks overlap on two streams, so the sums exceed the wall time).
+ * sum over those launches (kernels of different chunks and calls overlap on several streams, so the sums exceed the wall time).
  * Returns MI_ERR_INVALID past the last index: iterate from 0 until it fails.  *name is a static string. */
 int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms_total, int* launches);
 /* The same for an earlier call: age 1 = the call before the last one, age 2 = the one before that (while the event set has
