@@ -74,9 +74,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of audio to rank 0 (N>1)")
     ap.add_argument("--diag", action="store_true", help="print the time-parallel path's per-channel counters to stderr")
     ap.add_argument("--no-overlap", action="store_true", help="do not let consecutive steps overlap (MI_OPT_EARLY_INPUT off)")
-    ap.add_argument("--workload", choices=["config2", "config3", "config4"], default="config2",
+    ap.add_argument("--workload", choices=["config2", "config3", "config4", "am64"], default="config2",
                     help="config2 = BASELINE configs[1], the bench line (default); config3 = 1 stream x 32 mixed AM/NFM/CTCSS channels at fft 2048; "
-                         "config4 = 64 streams x the config-3 plan at fft 512 (extra measurements, not the driver's line)")
+                         "config4 = 64 streams x the config-3 plan at fft 512; am64 = 64 streams x the config-2 plan (extra measurements, not the driver's line)")
     args = ap.parse_args()
 
     import torch
@@ -97,6 +97,12 @@ def main():
     nstreams, fft_log = 1, 9
     if args.workload == "config2":
         centre, chans = pkg.config2_channels()
+    elif args.workload == "am64":
+        centre, chans = pkg.config2_channels()
+        nstreams = 64
+        if args.seconds == 64.0:
+            args.seconds = 8.0
+        args.cpu_seconds = 0.0
     else:
         centre, chans = pkg.config3_channels()
         nstreams, fft_log = (1, 11) if args.workload == "config3" else (64, 9)
@@ -256,7 +262,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": {"config2": "BASELINE configs[1]: 1 device stream per GPU @ 2.56 MS/s u8 IQ, 8 AM channels, fft_size=512",
                                     "config3": "BASELINE configs[2]: 1 device stream, 32 channels mixed AM+NFM + CTCSS, fft_size=2048",
-                                    "config4": "BASELINE configs[3]: 64 device streams x 32 mixed channels per GPU, fft_size=512"}[args.workload],
+                                    "config4": "BASELINE configs[3]: 64 device streams x 32 mixed channels per GPU, fft_size=512",
+                                    "am64": "64 device streams x 8 AM channels per GPU, fft_size=512"}[args.workload],
                        "streams_per_gpu": nstreams, "channels": nch, "fft_size": 1 << fft_log, "capture_seconds_per_step": nbat / 8.0,
                        "audio_gather_to_rank0": bool(gathering), "gather_overlaps_next_step": bool(gathering),
                        "stage2_path": "time-parallel" if h.last_path()[0] == 1 else "serial"},
