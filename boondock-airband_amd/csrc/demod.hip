@@ -441,6 +441,76 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
           const float gre[4] = {cz0.x, cz0.z, cz1.x, cz1.z}, gim[4] = {cz0.y, cz0.w, cz1.y, cz1.w};
           float pend[4] = {0.f, 0.f, 0.f, 0.f};  // waveout of the group, stored together at its end
           int flushed = 0;                        // outputs [0, flushed) already went out one by one (a fade rewrote them)
+          // Idle channel: CLOSED, and no sample of the group lifts pre_filter_.capped_ to the squelch level.  Then the four
+          // steps only move the averages, the noise floor, the closed-sample counter and the squelch ring (squelch.cpp:
+          // 442-449, 195-246 with every branch not taken); tried on copies, committed only if it held for all four.
+          bool idle = false;
+          if (c.s.current_state == SQ_CLOSED && c.s.next_state == SQ_CLOSED) {
+              ChanState& s = c.s;
+              float nf = s.noise_floor, cap = s.moving_avg_cap, full = s.pre_full, capd = s.pre_capped, cache = s.squelch_level_cache;
+              uint32_t sc = s.sample_count, closed = s.closed_sample_count, recent = s.recent_open_count;
+              int head = s.buffer_head, tail = s.buffer_tail;
+              float ringv[4];
+              int ringi[4];
+              bool quiet = true;
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {
+                  if (closed < kRecentSampleSize) {
+                      closed++;
+                  } else if (closed == kRecentSampleSize) {
+                      recent = 0;
+                      cache = 0.0f;
+                  }
+                  tail = (tail + 1 == kSquelchRing) ? 0 : tail + 1;
+                  head = (head + 1 == kSquelchRing) ? 0 : head + 1;
+                  sc++;
+                  if ((sc & 15u) == 0) {
+                      const float new_factor = static_cast<float>(1.0 - static_cast<double>(0.97f));
+                      nf = nf * 0.97f + std_min(capd, nf) * new_factor + 1e-6f;
+                      cap = P.using_manual_level ? P.manual_cap : P.cap_factor * nf;
+                      cache = 0.0f;
+                  }
+                  update_avg(cap, full, capd, gx[m]);
+                  ringv[m] = capd * 0.9f;
+                  ringi[m] = head;
+                  float level;
+                  if (P.using_manual_level) {
+                      level = P.manual_signal_level;
+                  } else {
+                      if (cache == 0.0f)
+                          cache = ((recent >= kFlapOpensThreshold && P.flappy_signal_ratio < P.normal_signal_ratio) ? P.flappy_signal_ratio
+                                                                                                                    : P.normal_signal_ratio) * nf;
+                      level = cache;
+                  }
+                  quiet = quiet && !(capd >= level);
+              }
+              if (quiet) {
+                  idle = true;
+                  s.noise_floor = nf, s.moving_avg_cap = cap, s.pre_full = full, s.pre_capped = capd, s.squelch_level_cache = cache;
+                  s.sample_count = sc, s.closed_sample_count = closed, s.recent_open_count = recent;
+                  s.buffer_head = head, s.buffer_tail = tail;
+                  if (P.lowpass_enabled) {
+#pragma unroll
+                      for (int m = 0; m < 4; ++m)
+                          c.ring[ringi[m]] = ringv[m];
+                  }
+                  if (iqo) {
+                      float4* z = reinterpret_cast<float4*>(iqo + i0);
+                      z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                      z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                  }
+                  in_batch += 4;  // WAVE_BATCH is a multiple of 4: a batch ends at a group end
+                  if (in_batch == kWaveBatch) {
+                      a.axc[static_cast<size_t>(row) * a.axc_stride + batch] = batch_open ? MI_SIGNAL : MI_NO_SIGNAL;
+                      if (batch_open)
+                          c.s.active_counter++;
+                      batch_open = false;
+                      in_batch = 0;
+                      batch++;
+                  }
+              }
+          }
+          if (!idle) {
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             const uint32_t i = i0 + static_cast<uint32_t>(m);
@@ -571,6 +641,7 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
                 in_batch = 0;
                 batch++;
             }
+          }
           }
           if (flushed == 0) {
               const uint32_t v = kAgcExtra + i0;
