@@ -31,6 +31,20 @@ struct FftGeom {
     static constexpr int XN = N + N / 8;                   // padded exchange length (float2)
 };
 
+// Lanes of one FFT exchange data through their slot of `xch`.  Up to N = 512 they all sit in one wave (64 lanes x 8 points;
+// N = 256: two FFTs per wave), whose LDS operations execute in order: a wave-level fence orders the exchange, and the four
+// waves of a workgroup never wait for each other inside the window loop.  Larger FFTs span waves and need the barrier.
+template <int L>
+__device__ __forceinline__ void fft_sync() {
+    if constexpr ((1 << L) / 8 <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ int xpad(int p) {
     return p + (p >> 3);
 }
@@ -138,7 +152,7 @@ __device__ __forceinline__ void later_passes(float2 (&x)[8], const float2 (&twr)
 #pragma unroll
             for (int ri = 0; ri < P::G; ++ri)
                 xch[xpad(P::pos(tau, gi, ri))] = x[gi * P::G + ri];
-        __syncthreads();
+        fft_sync<L>();
         later_passes<L, K + 1>(x, twr, xch, tau);
     }
 }
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             xch[xpad(tau * 8 + r)] = x[r];
-        __syncthreads();
+        fft_sync<L>();
         later_passes<L, 1>(x, twr, xch, tau);
         // natural-order spectrum now sits in xch: pick the channel bins (rtl_airband.cpp:505-511)
         if (active) {
@@ -270,8 +284,9 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
                 }
             }
         }
-        __syncthreads();
+        fft_sync<L>();  // the slot is rewritten by the next window's pass 0
     }
+    __syncthreads();  // the staged rows were written by every wave
 
     // ---- LDS -> HBM: contiguous rows of the planes ----
     for (int idx = tid; idx < a.nch * TW; idx += BLOCK) {
