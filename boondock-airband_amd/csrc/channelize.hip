@@ -185,7 +185,9 @@ __device__ __forceinline__ float2 fetch_sample(const unsigned char* __restrict__
     return v;
 }
 
-template <int L, int SFMT>
+// PRUNE: stages 4 .. L only produce the residues the picked bins need (PrunePlan); xch then holds two node buffers per FFT
+// slot instead of the padded exchange array, and the spectrum is never complete (no AFC with this instantiation).
+template <int L, int SFMT, bool PRUNE>
 __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const ChannelizeArgs a) {
     using Gm = FftGeom<L>;
     constexpr int N = Gm::N, TPF = Gm::TPF, F = Gm::F, TW = Gm::TW, XN = Gm::XN, BLOCK = Gm::BLOCK;
@@ -201,8 +203,17 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
     unsigned char* span = lds;
     float* lut = reinterpret_cast<float*>(lds + span_alloc);
     float2* xch_all = reinterpret_cast<float2*>(lds + span_alloc + 1024);
-    float* out_mag = reinterpret_cast<float*>(xch_all + F * XN);
+    const int slot_len = PRUNE ? 2 * a.prune.bufsz : XN;  // float2 per FFT slot
+    float* out_mag = reinterpret_cast<float*>(xch_all + F * slot_len);
     float2* out_iq = reinterpret_cast<float2*>(out_mag + a.nch * TW);
+    float4* ent = reinterpret_cast<float4*>(out_iq + a.n_iq_rows * TW);  // PRUNE: node entries, then the channels' ranks
+    int* crank = reinterpret_cast<int*>(ent + (PRUNE ? a.prune.nentries : 0));
+    if constexpr (PRUNE) {
+        for (int i = tid; i < a.prune.nentries; i += BLOCK)
+            ent[i] = a.prune_ent[i];
+        for (int i = tid; i < a.nch; i += BLOCK)
+            crank[i] = a.prune_rank[i];
+    }
 
     // ---- HBM -> LDS: the byte span of this tile, each byte read once, 16 B per lane ----
     const unsigned char* gbase = a.iq + static_cast<size_t>(stream) * a.stream_stride;
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
     // ---- per-lane constants: window coefficients of the 8 samples this lane converts, twiddles ----
     const int f = tid / TPF;
     const int tau = tid - f * TPF;
-    float2* xch = xch_all + f * XN;
+    float2* xch = xch_all + f * slot_len;
     const int nrev = (L > 3) ? static_cast<int>(__brev(static_cast<unsigned>(tau)) >> (32 - (L - 3))) : 0;
     int nidx[8];
     float wreg[8];
@@ -260,6 +271,49 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
         for (int r = 0; r < 8; ++r)
             x[r] = fetch_sample<SFMT>(span, wbyte + nidx[r] * BPS2, lut, a.conv_scale, wreg[r]);
         pass0(x, w8, w83);
+        if constexpr (PRUNE) {
+            // stage 3 keeps the residues in R_3 (lane tau = block tau of 8); then stage by stage, a node per lane and trip
+            float2* cur = xch;
+            float2* nxt = xch + a.prune.bufsz;
+            const int m3 = a.prune.m[3];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (a.prune.rank3[r] >= 0)
+                    cur[tau * m3 + a.prune.rank3[r]] = x[r];
+            fft_sync<L>();
+#pragma unroll 1
+            for (int s = 4; s <= L; ++s) {
+                const int m = a.prune.m[s], sh = a.prune.sh[s], mp = a.prune.m[s - 1];
+                const int total = (N >> s) << sh;
+                const float4* __restrict__ es = ent + a.prune.ent_off[s];
+                for (int n = tau; n < total; n += TPF) {
+                    const int b = n >> sh, j = n & ((1 << sh) - 1);
+                    if (j < m) {
+                        const float4 e = es[j];
+                        const int src = __float_as_int(e.w);
+                        const float2 a0 = cur[(2 * b) * mp + src], b0 = cur[(2 * b + 1) * mp + src];
+                        // the butterfly half of bfly(): t = w b, out = a +/- t (multiplying by +/-1 is exact)
+                        const float tr = __builtin_fmaf(-b0.y, e.y, b0.x * e.x);
+                        const float ti = __builtin_fmaf(b0.y, e.x, b0.x * e.y);
+                        nxt[b * m + j] = make_float2(a0.x + e.z * tr, a0.y + e.z * ti);
+                    }
+                }
+                fft_sync<L>();
+                float2* t = cur;
+                cur = nxt;
+                nxt = t;
+            }
+            // cur[rank] = X[bin] for every picked bin (rtl_airband.cpp:505-511)
+            if (active) {
+                for (int c = tau; c < a.nch; c += TPF) {
+                    const ChanParams& cp = a.cp[c];
+                    const float2 v = cur[crank[c]];
+                    out_mag[c * TW + wi] = sqrtf(v.x * v.x + v.y * v.y);
+                    if (cp.iq_row >= 0)
+                        out_iq[cp.iq_row * TW + wi] = v;
+                }
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             xch[xpad(tau * 8 + r)] = x[r];
@@ -283,6 +337,7 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
                     sq[k] = v.x * v.x + v.y * v.y;
                 }
             }
+        }
         }
         fft_sync<L>();  // the slot is rewritten by the next window's pass 0
     }
@@ -309,16 +364,18 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
     }
 }
 
-template <int L, int SFMT>
+template <int L, int SFMT, bool PRUNE>
 hipError_t launch_one(const ChannelizeArgs& a, int nstreams, hipStream_t s) {
     using Gm = FftGeom<L>;
     constexpr int BPS2 = (SFMT == MI_SFMT_S16 ? 4 : (SFMT == MI_SFMT_F32 ? 8 : 2));
     const unsigned span_alloc = (static_cast<unsigned>(Gm::TW - 1) * a.hop_bytes + Gm::N * BPS2 + 16 + 15) & ~15u;
-    const size_t lds = span_alloc + 1024 + static_cast<size_t>(Gm::F) * Gm::XN * 8 + static_cast<size_t>(a.nch) * Gm::TW * 4 +
-                       static_cast<size_t>(a.n_iq_rows) * Gm::TW * 8;
+    const size_t slot_len = PRUNE ? 2 * static_cast<size_t>(a.prune.bufsz) : static_cast<size_t>(Gm::XN);
+    const size_t lds = span_alloc + 1024 + static_cast<size_t>(Gm::F) * slot_len * 8 + static_cast<size_t>(a.nch) * Gm::TW * 4 +
+                       static_cast<size_t>(a.n_iq_rows) * Gm::TW * 8 +
+                       (PRUNE ? static_cast<size_t>(a.prune.nentries) * 16 + static_cast<size_t>(a.nch) * 4 : 0);
     if (lds > 160 * 1024)
         return hipErrorInvalidValue;
-    auto kern = k_channelize<L, SFMT>;
+    auto kern = k_channelize<L, SFMT, PRUNE>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess)
@@ -329,15 +386,22 @@ hipError_t launch_one(const ChannelizeArgs& a, int nstreams, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int L>
-hipError_t launch_fmt(const ChannelizeArgs& a, int sfmt, int nstreams, hipStream_t s) {
+template <int L, bool PRUNE>
+hipError_t launch_fmt2(const ChannelizeArgs& a, int sfmt, int nstreams, hipStream_t s) {
     switch (sfmt) {
-        case MI_SFMT_U8: return launch_one<L, MI_SFMT_U8>(a, nstreams, s);
-        case MI_SFMT_S8: return launch_one<L, MI_SFMT_S8>(a, nstreams, s);
-        case MI_SFMT_S16: return launch_one<L, MI_SFMT_S16>(a, nstreams, s);
-        case MI_SFMT_F32: return launch_one<L, MI_SFMT_F32>(a, nstreams, s);
+        case MI_SFMT_U8: return launch_one<L, MI_SFMT_U8, PRUNE>(a, nstreams, s);
+        case MI_SFMT_S8: return launch_one<L, MI_SFMT_S8, PRUNE>(a, nstreams, s);
+        case MI_SFMT_S16: return launch_one<L, MI_SFMT_S16, PRUNE>(a, nstreams, s);
+        case MI_SFMT_F32: return launch_one<L, MI_SFMT_F32, PRUNE>(a, nstreams, s);
     }
     return hipErrorInvalidValue;
+}
+template <int L>
+hipError_t launch_fmt(const ChannelizeArgs& a, int sfmt, int nstreams, hipStream_t s) {
+    // the pruned graph has no complete spectrum: AFC launches (they want it) and handles without a prune plan take the full one
+    if (a.prune.enabled && a.prune_ent && a.prune_rank && !a.afc_spec && !a.st)
+        return launch_fmt2<L, true>(a, sfmt, nstreams, s);
+    return launch_fmt2<L, false>(a, sfmt, nstreams, s);
 }
 
 }  // namespace

@@ -60,6 +60,9 @@ struct ChannelizeArgs {
     const ChanParams* cp;
     int nch, n_iq_rows;
     unsigned* xmax;  // [nstreams*nch] running max of the magnitudes written (bit pattern; values are >= 0), or null
+    PrunePlan prune;          // stage-1 graph pruning (plan.hpp); prune.enabled selects the pruned instantiation
+    const float4* prune_ent;  // its node entries
+    const int* prune_rank;    // [nch] rank of each channel's bin among the picked bins
     const ChanState* st;  // AFC handles: the bin of (stream, channel) is st[..].afc_bin; null: ChanParams::bin
     float* afc_spec;      // AFC handles: [nstreams][fft_size] re^2+im^2 of the LAST window of the launch (AFC::square), or null
 };

@@ -97,6 +97,8 @@ struct mi_demod {
     // device memory
     float* d_window = nullptr;
     float* d_tw = nullptr;
+    float4* d_prune_ent = nullptr;  // stage-1 pruning tables (plan.prune)
+    int* d_prune_rank = nullptr;
     float* d_levels = nullptr;
     float* d_sin = nullptr;
     float* d_cos = nullptr;
@@ -150,6 +152,16 @@ int tp_env() {
 }
 constexpr int kTpMinBatches = 8;  // below this the segments are too few to pay for the extra passes
 
+// The pruned stage-1 graph (PrunePlan) is bit-exact but, one node per lane and a wave-level fence per stage, measured
+// slower than the full radix-8 passes on MI355X (0.45 vs 0.35 ms per 20 s of one stream): off unless MI_AIRBAND_PRUNE=1.
+bool prune_wanted() {
+    static const bool on = [] {
+        const char* e = std::getenv("MI_AIRBAND_PRUNE");
+        return e && std::atoi(e) != 0;
+    }();
+    return on;
+}
+
 int lanes_per_wave_for(int rows) {
     // up to kUniRows waves keep one channel each (the uniform instantiation of k_demod); beyond that pack lanes
     static const int uni_rows = [] {
@@ -180,6 +192,10 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     ca.plane_off = h->first_call ? 0 : mi::kAgcExtra;
     ca.window = h->d_window;
     ca.tw = h->d_tw;
+    ca.prune = h->plan.prune;
+    ca.prune.enabled = (ca.prune.enabled && prune_wanted()) ? 1 : 0;
+    ca.prune_ent = h->d_prune_ent;
+    ca.prune_rank = h->d_prune_rank;
     ca.levels = h->d_levels;
     ca.conv_scale = h->plan.conv_scale;
     ca.cp = h->d_cp;
@@ -490,7 +506,7 @@ void mi_demod_destroy(mi_demod* h) {
         return;
     (void)hipSetDevice(h->gpu);
     (void)hipDeviceSynchronize();  // calls may still be in flight on the handle's own streams
-    void* ptrs[] = {h->d_window, h->d_tw,   h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx, h->d_carry,
+    void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_ent, h->d_prune_rank, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx, h->d_carry,
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc,
                     h->d_rows,   h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_fullbound, h->d_afc_spec};
     for (void* p : ptrs)
@@ -613,6 +629,12 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     TRY_OR_BAIL(dalloc(&h->d_stats, rows));
     TRY_OR_BAIL(hipMemcpy(h->d_window, p.window.data(), p.window.size() * 4, hipMemcpyHostToDevice));
     TRY_OR_BAIL(hipMemcpy(h->d_tw, p.tw.data(), p.tw.size() * 4, hipMemcpyHostToDevice));
+    if (p.prune.enabled && !p.prune_entries.empty()) {
+        TRY_OR_BAIL(dalloc(&h->d_prune_ent, p.prune_entries.size() / 4));
+        TRY_OR_BAIL(hipMemcpy(h->d_prune_ent, p.prune_entries.data(), p.prune_entries.size() * 4, hipMemcpyHostToDevice));
+        TRY_OR_BAIL(dalloc(&h->d_prune_rank, p.prune_chan_rank.size()));
+        TRY_OR_BAIL(hipMemcpy(h->d_prune_rank, p.prune_chan_rank.data(), p.prune_chan_rank.size() * 4, hipMemcpyHostToDevice));
+    }
     TRY_OR_BAIL(hipMemcpy(h->d_levels, p.levels.data(), 256 * 4, hipMemcpyHostToDevice));
     TRY_OR_BAIL(hipMemcpy(h->d_sin, p.sin_lut, 257 * 4, hipMemcpyHostToDevice));
     TRY_OR_BAIL(hipMemcpy(h->d_cos, p.cos_lut, 257 * 4, hipMemcpyHostToDevice));

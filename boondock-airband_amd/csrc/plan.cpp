@@ -3,6 +3,9 @@
 // (squelch decisions must be bit-exact).  Citations are /root/reference/src/<file>:<line>.
 #include "plan.hpp"
 
+#include <algorithm>
+#include <cstring>
+
 #include <cmath>
 #include <complex>
 #include <cstring>
@@ -273,6 +276,63 @@ int build_plan(const mi_device_cfg& dev, const mi_channel_cfg* chans, int nch, P
             dm *= 256.0 * 65536.0;
             c.dm_dphi = static_cast<uint32_t>(static_cast<int>(dm));
         }
+    }
+    // ---- stage-1 pruning (see PrunePlan) ----
+    {
+        PrunePlan& pr = p.prune;
+        pr = PrunePlan{};
+        p.prune_entries.clear();
+        p.prune_chan_rank.assign(static_cast<size_t>(nch), 0);
+        const int L = p.log2n, N = p.fft_size;
+        std::vector<std::vector<int>> R(static_cast<size_t>(L) + 1);
+        for (int s = 3; s <= L; ++s) {
+            std::vector<int>& r = R[static_cast<size_t>(s)];
+            for (const ChanParams& c : p.cp)
+                r.push_back(static_cast<int>(c.bin) & ((1 << s) - 1));
+            std::sort(r.begin(), r.end());
+            r.erase(std::unique(r.begin(), r.end()), r.end());
+        }
+        auto rank_of = [&](int s, int v) {
+            const std::vector<int>& r = R[static_cast<size_t>(s)];
+            return static_cast<int>(std::lower_bound(r.begin(), r.end(), v) - r.begin());
+        };
+        long nodes = 0;
+        int bufsz = 0;
+        for (int s = 3; s <= L; ++s) {
+            const int m = static_cast<int>(R[static_cast<size_t>(s)].size());
+            int sh = 0;
+            while ((1 << sh) < m)
+                ++sh;
+            pr.m[s] = m;
+            pr.sh[s] = sh;
+            bufsz = std::max(bufsz, (N >> s) * m);
+            if (s >= 4)
+                nodes += static_cast<long>(N >> s) * m;
+        }
+        for (int r = 0; r < 8; ++r)
+            pr.rank3[r] = std::binary_search(R[3].begin(), R[3].end(), r) ? rank_of(3, r) : -1;
+        for (int s = 4; s <= L; ++s) {
+            pr.ent_off[s] = static_cast<int32_t>(p.prune_entries.size() / 4);
+            const int h = 1 << (s - 1);
+            for (int v : R[static_cast<size_t>(s)]) {
+                const int lo = v & (h - 1);
+                const int e = lo * (N >> s);  // twiddle exponent of the butterfly, < N/2
+                const int32_t src = rank_of(s - 1, lo);
+                float bits;
+                std::memcpy(&bits, &src, 4);
+                p.prune_entries.push_back(p.tw[2 * static_cast<size_t>(e)]);
+                p.prune_entries.push_back(p.tw[2 * static_cast<size_t>(e) + 1]);
+                p.prune_entries.push_back(v >= h ? -1.0f : 1.0f);
+                p.prune_entries.push_back(bits);
+            }
+        }
+        for (int i = 0; i < nch; ++i)
+            p.prune_chan_rank[static_cast<size_t>(i)] = rank_of(L, static_cast<int>(p.cp[static_cast<size_t>(i)].bin));
+        pr.bufsz = (bufsz + 1) & ~1;  // (even: the slots of the node buffers stay 16-byte aligned)
+        pr.nentries = static_cast<int32_t>(p.prune_entries.size() / 4);
+        // worth it when the later stages shrink to well under half of the (L - 3) * N butterfly halves of the full graph;
+        // AFC walks the whole spectrum of a window, so those handles keep the full graph
+        pr.enabled = (!p.any_afc && nodes * 2 <= static_cast<long>(L - 3) * N) ? 1 : 0;
     }
     return MI_OK;
 }

@@ -44,6 +44,22 @@ struct ChanParams {
     uint32_t afc;       // channel_t.afc (0 = off .. 255), boondock_airband.h:258
 };
 
+// Pruning of the radix-2 DIT graph to the bins the channel plan picks (channelize.hip).  Stage s (blocks of 2^s) only has
+// to produce the residues R_s = { bin mod 2^s }; with m_s = |R_s| that is (N >> s) * m_s nodes instead of N.  Every node is
+// computed with the operations of the full graph, so the picked bins keep their bits.
+constexpr int kPruneMaxStage = 14;
+struct PrunePlan {
+    int32_t enabled;                   // 0: evaluate the full graph
+    int32_t m[kPruneMaxStage];         // m_s for s = 3 .. log2n
+    int32_t sh[kPruneMaxStage];        // log2 of the next power of two >= m_s (lane mapping)
+    int32_t ent_off[kPruneMaxStage];   // first entry of stage s in `entries` (s >= 4)
+    int32_t rank3[8];                  // rank of residue r in R_3, or -1 when stage 3 need not keep it
+    int32_t bufsz;                     // largest node count of a stage (per FFT slot, float2)
+    int32_t nentries;
+};
+// entry of node residue j at stage s: twiddle (x, y), sign of the butterfly half (z = +1 / -1), rank of its source residue in
+// R_(s-1) (w, as int bits)
+
 struct Plan {
     mi_device_cfg dev{};
     std::vector<mi_channel_cfg> chans;
@@ -62,6 +78,9 @@ struct Plan {
     float conv_scale = 0.f;           // 1.0f / fullscale (s16, f32)
     std::vector<ChanParams> cp;       // nch
     std::vector<float> ctcss_coeff;   // n_ctcss_rows x 2 x kMaxTones  (fast, slow)
+    PrunePlan prune{};                // stage-1 graph pruning (disabled when it would not pay, or with AFC)
+    std::vector<float> prune_entries; // 4 floats per entry
+    std::vector<int32_t> prune_chan_rank;  // per channel: rank of its bin in R_log2n
     float initial_noise_floor = 5.0f;
 };
 

@@ -561,3 +561,38 @@ def test_checkpoint_between_overlapping_calls_and_timing_ages(pkg, monkeypatch):
     assert_same(wo[0], owo, "audio")
     assert_same(rest_b[0][0].cpu().numpy(), rest_a[0][0].cpu().numpy(), "audio after restoring the checkpoint")
     assert_same(rest_b[0][1].cpu().numpy(), rest_a[0][1].cpu().numpy(), "flags after restoring the checkpoint")
+
+
+def test_pruned_stage1_graph_keeps_every_bit(pkg, tmp_path):
+    """MI_AIRBAND_PRUNE=1: stage 1 evaluates only the nodes of the radix-2 graph that feed the picked bins (PrunePlan).  Any
+    subset of the graph is computed with the same operations, so audio and raw I/Q stay bit-exact; run in a fresh process
+    because the switch is read once."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os\n"
+        f"sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
+        "import numpy as np\n"
+        "from conftest import load_package\n"
+        "from common import gen_iq, oracle_run, WAVE_BATCH\n"
+        "pkg = load_package()\n"
+        "for name in ('config2', 'config3'):\n"
+        "    centre, chans = getattr(pkg, name + '_channels')()\n"
+        "    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=9 if name == 'config2' else 11)\n"
+        "    nbat = 6\n"
+        "    kw = {} if name == 'config2' else dict(amp_q8=1024, active=lambda k: k % 4 != 2)\n"
+        "    iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=2, **kw)\n"
+        "    d = pkg.Demod(dev, chans, max_batches=nbat)\n"
+        "    wo, axc, iqo, _ = d.process([iq], nbat, want_iq=True)\n"
+        "    d.close()\n"
+        "    nb, owo, oaxc, oiq = oracle_run(dev, chans, iq, nbat, want_iq=True)\n"
+        "    assert np.array_equal(wo[0, :, :nbat * WAVE_BATCH], owo) and np.array_equal(axc[0], oaxc), name\n"
+        "    for c, ch in enumerate(chans):\n"
+        "        if ch.has_iq_outputs:\n"
+        "            assert np.array_equal(iqo[0, c].reshape(-1), oiq[c]), (name, c)\n"
+        "print('pruned ok')\n")
+    env = dict(os.environ, MI_AIRBAND_PRUNE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "pruned ok" in r.stdout, r.stdout + r.stderr
