@@ -165,11 +165,25 @@ __device__ __forceinline__ void load_all_tw(int tau, const float2* __restrict__ 
     }
 }
 
+// u8 samples without the level table: (b - 127.5f) / 127.5f as a product with the reciprocal and one fma correction step.  The
+// plan checks on the host, for all 256 values, that this reproduces the table the reference builds (rtl_airband.cpp:341-346)
+// bit for bit before it selects this instantiation -- a lookup is two random LDS reads per sample in a kernel the LDS bounds.
+constexpr int kSfmtU8Arith = 100;
+__device__ __forceinline__ float level_u8(float n) {
+    constexpr float d = 127.5f, rcp = 1.0f / 127.5f;
+    const float q0 = n * rcp;
+    return __builtin_fmaf(__builtin_fmaf(-q0, d, n), rcp, q0);
+}
+
 template <int SFMT>
 __device__ __forceinline__ float2 fetch_sample(const unsigned char* __restrict__ span, int byte_off, const float* __restrict__ lut, float scale,
                                                float w) {
     float2 v;
-    if constexpr (SFMT == MI_SFMT_U8 || SFMT == MI_SFMT_S8) {
+    if constexpr (SFMT == kSfmtU8Arith) {
+        const unsigned short b = *reinterpret_cast<const unsigned short*>(span + byte_off);
+        v.x = level_u8(static_cast<float>(b & 0xff) - 127.5f) * w;
+        v.y = level_u8(static_cast<float>(b >> 8) - 127.5f) * w;
+    } else if constexpr (SFMT == MI_SFMT_U8 || SFMT == MI_SFMT_S8) {
         const unsigned short b = *reinterpret_cast<const unsigned short*>(span + byte_off);
         v.x = lut[b & 0xff] * w;  // rtl_airband.cpp:473-474
         v.y = lut[b >> 8] * w;
@@ -185,9 +199,7 @@ __device__ __forceinline__ float2 fetch_sample(const unsigned char* __restrict__
     return v;
 }
 
-// PRUNE: stages 4 .. L only produce the residues the picked bins need (PrunePlan); xch then holds two node buffers per FFT
-// slot instead of the padded exchange array, and the spectrum is never complete (no AFC with this instantiation).
-template <int L, int SFMT, bool PRUNE>
+template <int L, int SFMT>
 __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const ChannelizeArgs a) {
     using Gm = FftGeom<L>;
     constexpr int N = Gm::N, TPF = Gm::TPF, F = Gm::F, TW = Gm::TW, XN = Gm::XN, BLOCK = Gm::BLOCK;
@@ -203,17 +215,8 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
     unsigned char* span = lds;
     float* lut = reinterpret_cast<float*>(lds + span_alloc);
     float2* xch_all = reinterpret_cast<float2*>(lds + span_alloc + 1024);
-    const int slot_len = PRUNE ? 2 * a.prune.bufsz : XN;  // float2 per FFT slot
-    float* out_mag = reinterpret_cast<float*>(xch_all + F * slot_len);
+    float* out_mag = reinterpret_cast<float*>(xch_all + F * XN);
     float2* out_iq = reinterpret_cast<float2*>(out_mag + a.nch * TW);
-    float4* ent = reinterpret_cast<float4*>(out_iq + a.n_iq_rows * TW);  // PRUNE: node entries, then the channels' ranks
-    int* crank = reinterpret_cast<int*>(ent + (PRUNE ? a.prune.nentries : 0));
-    if constexpr (PRUNE) {
-        for (int i = tid; i < a.prune.nentries; i += BLOCK)
-            ent[i] = a.prune_ent[i];
-        for (int i = tid; i < a.nch; i += BLOCK)
-            crank[i] = a.prune_rank[i];
-    }
 
     // ---- HBM -> LDS: the byte span of this tile, each byte read once, 16 B per lane ----
     const unsigned char* gbase = a.iq + static_cast<size_t>(stream) * a.stream_stride;
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
     // ---- per-lane constants: window coefficients of the 8 samples this lane converts, twiddles ----
     const int f = tid / TPF;
     const int tau = tid - f * TPF;
-    float2* xch = xch_all + f * slot_len;
+    float2* xch = xch_all + f * XN;
     const int nrev = (L > 3) ? static_cast<int>(__brev(static_cast<unsigned>(tau)) >> (32 - (L - 3))) : 0;
     int nidx[8];
     float wreg[8];
@@ -271,49 +274,6 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
         for (int r = 0; r < 8; ++r)
             x[r] = fetch_sample<SFMT>(span, wbyte + nidx[r] * BPS2, lut, a.conv_scale, wreg[r]);
         pass0(x, w8, w83);
-        if constexpr (PRUNE) {
-            // stage 3 keeps the residues in R_3 (lane tau = block tau of 8); then stage by stage, a node per lane and trip
-            float2* cur = xch;
-            float2* nxt = xch + a.prune.bufsz;
-            const int m3 = a.prune.m[3];
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if (a.prune.rank3[r] >= 0)
-                    cur[tau * m3 + a.prune.rank3[r]] = x[r];
-            fft_sync<L>();
-#pragma unroll 1
-            for (int s = 4; s <= L; ++s) {
-                const int m = a.prune.m[s], sh = a.prune.sh[s], mp = a.prune.m[s - 1];
-                const int total = (N >> s) << sh;
-                const float4* __restrict__ es = ent + a.prune.ent_off[s];
-                for (int n = tau; n < total; n += TPF) {
-                    const int b = n >> sh, j = n & ((1 << sh) - 1);
-                    if (j < m) {
-                        const float4 e = es[j];
-                        const int src = __float_as_int(e.w);
-                        const float2 a0 = cur[(2 * b) * mp + src], b0 = cur[(2 * b + 1) * mp + src];
-                        // the butterfly half of bfly(): t = w b, out = a +/- t (multiplying by +/-1 is exact)
-                        const float tr = __builtin_fmaf(-b0.y, e.y, b0.x * e.x);
-                        const float ti = __builtin_fmaf(b0.y, e.x, b0.x * e.y);
-                        nxt[b * m + j] = make_float2(a0.x + e.z * tr, a0.y + e.z * ti);
-                    }
-                }
-                fft_sync<L>();
-                float2* t = cur;
-                cur = nxt;
-                nxt = t;
-            }
-            // cur[rank] = X[bin] for every picked bin (rtl_airband.cpp:505-511)
-            if (active) {
-                for (int c = tau; c < a.nch; c += TPF) {
-                    const ChanParams& cp = a.cp[c];
-                    const float2 v = cur[crank[c]];
-                    out_mag[c * TW + wi] = sqrtf(v.x * v.x + v.y * v.y);
-                    if (cp.iq_row >= 0)
-                        out_iq[cp.iq_row * TW + wi] = v;
-                }
-            }
-        } else {
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             xch[xpad(tau * 8 + r)] = x[r];
@@ -337,7 +297,6 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
                     sq[k] = v.x * v.x + v.y * v.y;
                 }
             }
-        }
         }
         fft_sync<L>();  // the slot is rewritten by the next window's pass 0
     }
@@ -364,18 +323,229 @@ __global__ __launch_bounds__(FftGeom<L>::BLOCK) void k_channelize(const Channeli
     }
 }
 
-template <int L, int SFMT, bool PRUNE>
+// ---- N = 512 with the graph pruned to the picked bins (PrunePlan) ----
+// A wave takes kGW windows at a time.  Pass 0 (stages 1-3) is the full one, a window per trip: the conversion x window of all
+// 512 samples is needed whatever is picked.  It keeps only the residues R_3 of every block of 8.  Pass 1 (stages 4-6) then
+// has 8 * m3 radix-8 work items per window instead of 64 -- (block of 64, residue in R_3) -- and pass 2 (stages 7-9) has m6:
+// the items of the kGW windows are packed onto the lanes (class = lane & (classes - 1), so a lane's twiddles and output
+// slots never change), each item runs the same Pass<9, K>::run butterflies on the same operands as the full kernel.
+// Exchange buffers per window: b0[row ri][block hi * m3 + j] (row stride rs1), b1[row ri][j2] (rs2), b2[rank of the bin].
+constexpr int kGW = 2;
+
+template <int SFMT>
+__global__ __launch_bounds__(256, 4) void k_channelize9p(const ChannelizeArgs a) {
+    constexpr int L = 9, N = 512, TW = FftGeom<9>::TW, BLOCK = 256, NWAVE = 4;
+    constexpr int BPS2 = (SFMT == MI_SFMT_S16 ? 4 : (SFMT == MI_SFMT_F32 ? 8 : 2));
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int stream = blockIdx.y;
+    const unsigned w0 = blockIdx.x * TW;
+    const int nw = min(static_cast<unsigned>(TW), a.nfft - w0);
+    const PrunePlan& pp = a.prune;
+    const int m3 = pp.m3, sh3 = pp.sh3, m6 = pp.m6, sh6 = pp.sh6, m9 = pp.m9, rs1 = pp.rs1, rs2 = pp.rs2;
+    const int b0len = 8 * rs1, b2len = (m9 + 1) & ~1;  // float2 per window; b1 reuses b0's rows (rs2 <= rs1)
+    const int b1len = b0len;
+    const int wlen = kGW * (b0len + b2len);  // float2 per wave
+
+    const unsigned span_alloc = (static_cast<unsigned>(TW - 1) * a.hop_bytes + N * BPS2 + 16 + 15) & ~15u;
+    unsigned char* span = lds;
+    float* lut = reinterpret_cast<float*>(lds + span_alloc);
+    float2* xw = reinterpret_cast<float2*>(lds + span_alloc + 1024) + wave * wlen;
+    float* out_mag = reinterpret_cast<float*>(reinterpret_cast<float2*>(lds + span_alloc + 1024) + NWAVE * wlen);
+    float2* out_iq = reinterpret_cast<float2*>(out_mag + a.nch * TW);
+    float2* b0 = xw;
+    float2* b1 = b0;
+    float2* b2 = b0 + kGW * b0len;
+
+    // ---- HBM -> LDS: the byte span of this tile, each byte read once, 16 B per lane ----
+    const unsigned char* gbase = a.iq + static_cast<size_t>(stream) * a.stream_stride;
+    const long long byte0 = static_cast<long long>(w0) * a.hop_bytes;
+    const unsigned mis = static_cast<unsigned>(reinterpret_cast<uintptr_t>(gbase + byte0) & 15);
+    const unsigned need = static_cast<unsigned>(nw - 1) * a.hop_bytes + N * BPS2;
+    const unsigned nchunks = (mis + need + 15) >> 4;
+    for (unsigned c = tid; c < nchunks; c += BLOCK) {
+        const long long off = byte0 - mis + 16ll * c;
+        uint4 v;
+        if (off >= 0 && off + 16 <= static_cast<long long>(a.valid_bytes)) {
+            v = *reinterpret_cast<const uint4*>(gbase + off);
+        } else {
+            unsigned char tmp[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long long o = off + i;
+                tmp[i] = (o >= 0 && o < static_cast<long long>(a.valid_bytes)) ? gbase[o] : 0;
+            }
+            v = *reinterpret_cast<uint4*>(tmp);
+        }
+        *reinterpret_cast<uint4*>(span + 16 * c) = v;
+    }
+    if constexpr (SFMT == MI_SFMT_U8 || SFMT == MI_SFMT_S8) {
+        for (int i = tid; i < 256; i += BLOCK)
+            lut[i] = a.levels[i];
+    }
+
+    // ---- per-lane constants ----
+    const int tau = lane;  // pass 0: lane = block of 8 at stage 3
+    const int nrev = static_cast<int>(__brev(static_cast<unsigned>(tau)) >> (32 - (L - 3)));
+    int nidx[8];
+    float wreg[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int rev3 = ((r & 1) << 2) | (r & 2) | ((r >> 2) & 1);
+        nidx[r] = rev3 * (N / 8) + nrev;  // natural sample index = bitrev_9(8 tau + r)
+        wreg[r] = a.window[nidx[r]];
+    }
+    const float2* tw = reinterpret_cast<const float2*>(a.tw);
+    const float2 w8 = tw[N / 8], w83 = tw[3 * N / 8];
+    // the lane's item class in pass 1 / pass 2: 7 twiddles and 8 output slots each
+    const int j1 = lane & ((1 << sh3) - 1), j2 = lane & ((1 << sh6) - 1);
+    float2 t1[7], t2[7];
+    unsigned o1[2], o2[2];  // 8 output slots each, a byte per slot (0xff = not needed)
+    {
+        const float* c1 = a.prune_t1 + static_cast<size_t>(j1) * kPruneClassWords;
+        const float* c2 = a.prune_t2 + static_cast<size_t>(j2) * kPruneClassWords;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            t1[k] = make_float2(c1[2 * k], c1[2 * k + 1]);
+            t2[k] = make_float2(c2[2 * k], c2[2 * k + 1]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            o1[k] = __float_as_uint(c1[14 + k]);
+            o2[k] = __float_as_uint(c2[14 + k]);
+        }
+    }
+    const int ipf1 = 8 << sh3;  // padded items of pass 1 per window (block hi = 0..7, class)
+    const int hi1 = (lane & (ipf1 - 1)) >> sh3;
+    __syncthreads();
+
+    for (int wbase = wave * kGW; wbase < nw; wbase += NWAVE * kGW) {
+        // ---- pass 0, one window per trip ----
+#pragma unroll 1
+        for (int g = 0; g < kGW; ++g) {
+            const int wi = wbase + g;
+            const int wbyte = static_cast<int>(mis) + (wi < nw ? wi : 0) * static_cast<int>(a.hop_bytes);
+            float2 x[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                x[r] = fetch_sample<SFMT>(span, wbyte + nidx[r] * BPS2, lut, a.conv_scale, wreg[r]);
+            pass0(x, w8, w83);
+            float2* d = b0 + g * b0len + (tau & 7) * rs1 + (tau >> 3) * m3;  // block tau = 8 hi + ri of pass 1
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (pp.rank3[r] >= 0)
+                    d[pp.rank3[r]] = x[r];
+        }
+        fft_sync<L>();
+        // ---- pass 1: kGW * ipf1 items ----
+        for (int q = lane; q < kGW * ipf1; q += 64) {
+            const int g = q >> (3 + sh3);
+            if (j1 < m3) {
+                const float2* src = b0 + g * b0len + hi1 * m3 + j1;
+                float2 x[8];
+#pragma unroll
+                for (int ri = 0; ri < 8; ++ri)
+                    x[ri] = src[ri * rs1];
+                Pass<L, 1>::run(x, t1);
+                fft_sync<L>();  // b1 lies over the rows just read
+                float2* dst = b1 + g * b1len + hi1 * rs2;  // block hi1 of 64 = row of pass 2
+#pragma unroll
+                for (int ri = 0; ri < 8; ++ri) {
+                    const unsigned o = (o1[ri >> 2] >> (8 * (ri & 3))) & 0xffu;
+                    if (o != 0xffu)
+                        dst[o] = x[ri];
+                }
+            }
+        }
+        fft_sync<L>();
+        // ---- pass 2: kGW << sh6 items ----
+        for (int q = lane; q < (kGW << sh6); q += 64) {
+            const int g = q >> sh6;
+            if (j2 < m6) {
+                const float2* src = b1 + g * b1len + j2;
+                float2 x[8];
+#pragma unroll
+                for (int ri = 0; ri < 8; ++ri)
+                    x[ri] = src[ri * rs2];
+                Pass<L, 2>::run(x, t2);
+                float2* dst = b2 + g * b2len;
+#pragma unroll
+                for (int ri = 0; ri < 8; ++ri) {
+                    const unsigned o = (o2[ri >> 2] >> (8 * (ri & 3))) & 0xffu;
+                    if (o != 0xffu)
+                        dst[o] = x[ri];
+                }
+            }
+        }
+        fft_sync<L>();
+        // ---- the picked bins of the kGW windows (rtl_airband.cpp:505-511) ----
+        for (int idx = lane; idx < kGW * a.nch; idx += 64) {
+            const int g = idx / a.nch, c = idx - g * a.nch;
+            const int wi = wbase + g;
+            if (wi < nw) {
+                const float2 v = b2[g * b2len + a.prune_rank[c]];
+                out_mag[c * TW + wi] = sqrtf(v.x * v.x + v.y * v.y);
+                const int iq_row = a.cp[c].iq_row;
+                if (iq_row >= 0)
+                    out_iq[iq_row * TW + wi] = v;
+            }
+        }
+        fft_sync<L>();
+    }
+    __syncthreads();  // the staged rows were written by every wave
+
+    // ---- LDS -> HBM: contiguous rows of the planes ----
+    for (int idx = tid; idx < a.nch * TW; idx += BLOCK) {
+        const int c = idx / TW, i = idx - c * TW;
+        if (i < nw)
+            a.mag[(static_cast<size_t>(stream) * a.nch + c) * a.plane_stride + a.plane_off + w0 + i] = out_mag[idx];
+    }
+    if (a.xmax) {
+        for (int c = tid; c < a.nch; c += BLOCK) {
+            float m = 0.0f;
+            for (int i = 0; i < nw; ++i)
+                m = fmaxf(m, out_mag[c * TW + i]);
+            atomicMax(a.xmax + static_cast<size_t>(stream) * a.nch + c, __float_as_uint(m));
+        }
+    }
+    for (int idx = tid; idx < a.n_iq_rows * TW; idx += BLOCK) {
+        const int c = idx / TW, i = idx - c * TW;
+        if (i < nw)
+            a.cplx[(static_cast<size_t>(stream) * a.n_iq_rows + c) * a.plane_stride + a.plane_off + w0 + i] = out_iq[idx];
+    }
+}
+
+template <int SFMT>
+hipError_t launch_9p(const ChannelizeArgs& a, int nstreams, hipStream_t s) {
+    using Gm = FftGeom<9>;
+    constexpr int BPS2 = (SFMT == MI_SFMT_S16 ? 4 : (SFMT == MI_SFMT_F32 ? 8 : 2));
+    const unsigned span_alloc = (static_cast<unsigned>(Gm::TW - 1) * a.hop_bytes + Gm::N * BPS2 + 16 + 15) & ~15u;
+    const size_t wlen = static_cast<size_t>(kGW) * (8 * a.prune.rs1 + ((a.prune.m9 + 1) & ~1));
+    const size_t lds = span_alloc + 1024 + 4 * wlen * 8 + static_cast<size_t>(a.nch) * Gm::TW * 4 + static_cast<size_t>(a.n_iq_rows) * Gm::TW * 8;
+    if (lds > 160 * 1024)
+        return hipErrorInvalidValue;
+    auto kern = k_channelize9p<SFMT>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess)
+            return e;
+    }
+    const dim3 grid((a.nfft + Gm::TW - 1) / Gm::TW, nstreams);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int L, int SFMT>
 hipError_t launch_one(const ChannelizeArgs& a, int nstreams, hipStream_t s) {
     using Gm = FftGeom<L>;
     constexpr int BPS2 = (SFMT == MI_SFMT_S16 ? 4 : (SFMT == MI_SFMT_F32 ? 8 : 2));
     const unsigned span_alloc = (static_cast<unsigned>(Gm::TW - 1) * a.hop_bytes + Gm::N * BPS2 + 16 + 15) & ~15u;
-    const size_t slot_len = PRUNE ? 2 * static_cast<size_t>(a.prune.bufsz) : static_cast<size_t>(Gm::XN);
-    const size_t lds = span_alloc + 1024 + static_cast<size_t>(Gm::F) * slot_len * 8 + static_cast<size_t>(a.nch) * Gm::TW * 4 +
-                       static_cast<size_t>(a.n_iq_rows) * Gm::TW * 8 +
-                       (PRUNE ? static_cast<size_t>(a.prune.nentries) * 16 + static_cast<size_t>(a.nch) * 4 : 0);
+    const size_t lds = span_alloc + 1024 + static_cast<size_t>(Gm::F) * Gm::XN * 8 + static_cast<size_t>(a.nch) * Gm::TW * 4 +
+                       static_cast<size_t>(a.n_iq_rows) * Gm::TW * 8;
     if (lds > 160 * 1024)
         return hipErrorInvalidValue;
-    auto kern = k_channelize<L, SFMT, PRUNE>;
+    auto kern = k_channelize<L, SFMT>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess)
@@ -386,22 +556,15 @@ hipError_t launch_one(const ChannelizeArgs& a, int nstreams, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int L, bool PRUNE>
-hipError_t launch_fmt2(const ChannelizeArgs& a, int sfmt, int nstreams, hipStream_t s) {
-    switch (sfmt) {
-        case MI_SFMT_U8: return launch_one<L, MI_SFMT_U8, PRUNE>(a, nstreams, s);
-        case MI_SFMT_S8: return launch_one<L, MI_SFMT_S8, PRUNE>(a, nstreams, s);
-        case MI_SFMT_S16: return launch_one<L, MI_SFMT_S16, PRUNE>(a, nstreams, s);
-        case MI_SFMT_F32: return launch_one<L, MI_SFMT_F32, PRUNE>(a, nstreams, s);
-    }
-    return hipErrorInvalidValue;
-}
 template <int L>
 hipError_t launch_fmt(const ChannelizeArgs& a, int sfmt, int nstreams, hipStream_t s) {
-    // the pruned graph has no complete spectrum: AFC launches (they want it) and handles without a prune plan take the full one
-    if (a.prune.enabled && a.prune_ent && a.prune_rank && !a.afc_spec && !a.st)
-        return launch_fmt2<L, true>(a, sfmt, nstreams, s);
-    return launch_fmt2<L, false>(a, sfmt, nstreams, s);
+    switch (sfmt) {
+        case MI_SFMT_U8: return a.conv_arith ? launch_one<L, kSfmtU8Arith>(a, nstreams, s) : launch_one<L, MI_SFMT_U8>(a, nstreams, s);
+        case MI_SFMT_S8: return launch_one<L, MI_SFMT_S8>(a, nstreams, s);
+        case MI_SFMT_S16: return launch_one<L, MI_SFMT_S16>(a, nstreams, s);
+        case MI_SFMT_F32: return launch_one<L, MI_SFMT_F32>(a, nstreams, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace
@@ -409,6 +572,16 @@ hipError_t launch_fmt(const ChannelizeArgs& a, int sfmt, int nstreams, hipStream
 hipError_t launch_channelize(const ChannelizeArgs& a, int log2n, int sfmt, int nstreams, hipStream_t s) {
     if (a.nfft == 0 || nstreams == 0)
         return hipSuccess;
+    // the pruned graph has no complete spectrum: AFC launches (they want one) take the full kernel
+    if (log2n == 9 && a.prune.enabled && a.prune_t1 && a.prune_t2 && a.prune_rank && !a.afc_spec && !a.st) {
+        switch (sfmt) {
+            case MI_SFMT_U8: return a.conv_arith ? launch_9p<kSfmtU8Arith>(a, nstreams, s) : launch_9p<MI_SFMT_U8>(a, nstreams, s);
+            case MI_SFMT_S8: return launch_9p<MI_SFMT_S8>(a, nstreams, s);
+            case MI_SFMT_S16: return launch_9p<MI_SFMT_S16>(a, nstreams, s);
+            case MI_SFMT_F32: return launch_9p<MI_SFMT_F32>(a, nstreams, s);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (log2n) {
         case 8: return launch_fmt<8>(a, sfmt, nstreams, s);
         case 9: return launch_fmt<9>(a, sfmt, nstreams, s);

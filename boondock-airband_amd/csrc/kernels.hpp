@@ -56,13 +56,15 @@ struct ChannelizeArgs {
     const float* window;
     const float* tw;
     const float* levels;
+    int conv_arith;           // u8: the level table is reproduced by level_u8() (checked by the plan)
     float conv_scale;
     const ChanParams* cp;
     int nch, n_iq_rows;
     unsigned* xmax;  // [nstreams*nch] running max of the magnitudes written (bit pattern; values are >= 0), or null
     PrunePlan prune;          // stage-1 graph pruning (plan.hpp); prune.enabled selects the pruned instantiation
-    const float4* prune_ent;  // its node entries
-    const int* prune_rank;    // [nch] rank of each channel's bin among the picked bins
+    const float* prune_t1;    // its item-class tables of pass 1 / pass 2 (kPruneClassWords floats per class)
+    const float* prune_t2;
+    const int* prune_rank;    // [nch] rank of each channel's bin among the distinct picked bins
     const ChanState* st;  // AFC handles: the bin of (stream, channel) is st[..].afc_bin; null: ChanParams::bin
     float* afc_spec;      // AFC handles: [nstreams][fft_size] re^2+im^2 of the LAST window of the launch (AFC::square), or null
 };

@@ -97,7 +97,8 @@ struct mi_demod {
     // device memory
     float* d_window = nullptr;
     float* d_tw = nullptr;
-    float4* d_prune_ent = nullptr;  // stage-1 pruning tables (plan.prune)
+    float* d_prune_t1 = nullptr;  // stage-1 pruning tables (plan.prune)
+    float* d_prune_t2 = nullptr;
     int* d_prune_rank = nullptr;
     float* d_levels = nullptr;
     float* d_sin = nullptr;
@@ -152,12 +153,19 @@ int tp_env() {
 }
 constexpr int kTpMinBatches = 8;  // below this the segments are too few to pay for the extra passes
 
-// The pruned stage-1 graph (PrunePlan) is bit-exact but, one node per lane and a wave-level fence per stage, measured
-// slower than the full radix-8 passes on MI355X (0.45 vs 0.35 ms per 20 s of one stream): off unless MI_AIRBAND_PRUNE=1.
+// The pruned stage-1 graph (PrunePlan, k_channelize9p) is bit-exact and about 10 % faster where it applies (N = 512, no AFC,
+// few residues among the bins): on unless MI_AIRBAND_PRUNE=0.
+bool conv_lut_forced() {  // MI_AIRBAND_CONV_LUT=1: keep the level table for u8 (A/B measurement)
+    static const bool on = [] {
+        const char* e = std::getenv("MI_AIRBAND_CONV_LUT");
+        return e && std::atoi(e) != 0;
+    }();
+    return on;
+}
 bool prune_wanted() {
     static const bool on = [] {
         const char* e = std::getenv("MI_AIRBAND_PRUNE");
-        return e && std::atoi(e) != 0;
+        return !(e && *e && std::atoi(e) == 0);
     }();
     return on;
 }
@@ -194,9 +202,11 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     ca.tw = h->d_tw;
     ca.prune = h->plan.prune;
     ca.prune.enabled = (ca.prune.enabled && prune_wanted()) ? 1 : 0;
-    ca.prune_ent = h->d_prune_ent;
+    ca.prune_t1 = h->d_prune_t1;
+    ca.prune_t2 = h->d_prune_t2;
     ca.prune_rank = h->d_prune_rank;
     ca.levels = h->d_levels;
+    ca.conv_arith = (h->plan.conv_arith && !conv_lut_forced()) ? 1 : 0;
     ca.conv_scale = h->plan.conv_scale;
     ca.cp = h->d_cp;
     ca.nch = h->nch;
@@ -506,7 +516,7 @@ void mi_demod_destroy(mi_demod* h) {
         return;
     (void)hipSetDevice(h->gpu);
     (void)hipDeviceSynchronize();  // calls may still be in flight on the handle's own streams
-    void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_ent, h->d_prune_rank, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx, h->d_carry,
+    void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_t1, h->d_prune_t2, h->d_prune_rank, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx, h->d_carry,
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc,
                     h->d_rows,   h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_fullbound, h->d_afc_spec};
     for (void* p : ptrs)
@@ -629,9 +639,11 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     TRY_OR_BAIL(dalloc(&h->d_stats, rows));
     TRY_OR_BAIL(hipMemcpy(h->d_window, p.window.data(), p.window.size() * 4, hipMemcpyHostToDevice));
     TRY_OR_BAIL(hipMemcpy(h->d_tw, p.tw.data(), p.tw.size() * 4, hipMemcpyHostToDevice));
-    if (p.prune.enabled && !p.prune_entries.empty()) {
-        TRY_OR_BAIL(dalloc(&h->d_prune_ent, p.prune_entries.size() / 4));
-        TRY_OR_BAIL(hipMemcpy(h->d_prune_ent, p.prune_entries.data(), p.prune_entries.size() * 4, hipMemcpyHostToDevice));
+    if (p.prune.enabled) {
+        TRY_OR_BAIL(dalloc(&h->d_prune_t1, p.prune_t1.size()));
+        TRY_OR_BAIL(hipMemcpy(h->d_prune_t1, p.prune_t1.data(), p.prune_t1.size() * 4, hipMemcpyHostToDevice));
+        TRY_OR_BAIL(dalloc(&h->d_prune_t2, p.prune_t2.size()));
+        TRY_OR_BAIL(hipMemcpy(h->d_prune_t2, p.prune_t2.data(), p.prune_t2.size() * 4, hipMemcpyHostToDevice));
         TRY_OR_BAIL(dalloc(&h->d_prune_rank, p.prune_chan_rank.size()));
         TRY_OR_BAIL(hipMemcpy(h->d_prune_rank, p.prune_chan_rank.data(), p.prune_chan_rank.size() * 4, hipMemcpyHostToDevice));
     }

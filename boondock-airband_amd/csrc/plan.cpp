@@ -158,6 +158,18 @@ int build_plan(const mi_device_cfg& dev, const mi_channel_cfg* chans, int nch, P
         for (int i = 0; i < 256; ++i)
             p.levels[i] = (i - 127.5f) / 127.5f;
     }
+    p.conv_arith = false;
+    if (dev.sfmt == MI_SFMT_U8) {  // the same operations as level_u8() in channelize.hip, IEEE fp32 on both sides
+        volatile float d = 127.5f, rcp = 1.0f / 127.5f;
+        bool same = true;
+        for (int i = 0; i < 256 && same; ++i) {
+            const float n = static_cast<float>(i) - 127.5f;
+            volatile float q0 = n * rcp;
+            const float q1 = std::fmaf(std::fmaf(-q0, d, n), rcp, q0);
+            same = std::memcmp(&q1, &p.levels[static_cast<size_t>(i)], 4) == 0;
+        }
+        p.conv_arith = same;
+    }
     p.conv_scale = (dev.sfmt == MI_SFMT_S16 || dev.sfmt == MI_SFMT_F32) ? 1.0f / dev.fullscale : 0.0f;  // rtl_airband.cpp:425,443
 
     // sincosf_lut_init, util.cpp:105-110
@@ -281,58 +293,63 @@ int build_plan(const mi_device_cfg& dev, const mi_channel_cfg* chans, int nch, P
     {
         PrunePlan& pr = p.prune;
         pr = PrunePlan{};
-        p.prune_entries.clear();
+        p.prune_t1.clear();
+        p.prune_t2.clear();
         p.prune_chan_rank.assign(static_cast<size_t>(nch), 0);
         const int L = p.log2n, N = p.fft_size;
-        std::vector<std::vector<int>> R(static_cast<size_t>(L) + 1);
-        for (int s = 3; s <= L; ++s) {
-            std::vector<int>& r = R[static_cast<size_t>(s)];
-            for (const ChanParams& c : p.cp)
-                r.push_back(static_cast<int>(c.bin) & ((1 << s) - 1));
-            std::sort(r.begin(), r.end());
-            r.erase(std::unique(r.begin(), r.end()), r.end());
+        if (L == 9 && !p.any_afc) {
+            auto residues = [&](int s) {
+                std::vector<int> r;
+                for (const ChanParams& c : p.cp)
+                    r.push_back(static_cast<int>(c.bin) & ((1 << s) - 1));
+                std::sort(r.begin(), r.end());
+                r.erase(std::unique(r.begin(), r.end()), r.end());
+                return r;
+            };
+            const std::vector<int> R3 = residues(3), R6 = residues(6), R9 = residues(9);
+            auto rank_in = [](const std::vector<int>& r, int v) {
+                const auto it = std::lower_bound(r.begin(), r.end(), v);
+                return (it != r.end() && *it == v) ? static_cast<int>(it - r.begin()) : -1;
+            };
+            auto log2up = [](int m) {
+                int sh = 0;
+                while ((1 << sh) < m)
+                    ++sh;
+                return sh;
+            };
+            pr.m3 = static_cast<int>(R3.size()), pr.sh3 = log2up(pr.m3);
+            pr.m6 = static_cast<int>(R6.size()), pr.sh6 = log2up(pr.m6);
+            pr.m9 = static_cast<int>(R9.size());
+            pr.rs1 = 8 * pr.m3 + 1;  // pass 1 reads a row with consecutive lanes; the odd stride spreads pass 0's writes
+            pr.rs2 = pr.m6 + 1;
+            for (int r = 0; r < 8; ++r)
+                pr.rank3[r] = rank_in(R3, r);
+            // class tables: twiddles exactly as Pass<9, K>::load_tw builds them for lo = the class's residue
+            auto classes = [&](std::vector<float>& t, const std::vector<int>& Rin, int sh, int K, const std::vector<int>& Rout) {
+                const int S = 1 << (3 * K);
+                t.assign(static_cast<size_t>(1 << sh) * kPruneClassWords, 0.0f);
+                for (size_t j = 0; j < Rin.size(); ++j) {
+                    float* c = t.data() + j * kPruneClassWords;
+                    const int lo = Rin[j];
+                    for (int a = 0; a < 3; ++a)
+                        for (int mm = 0; mm < (1 << a); ++mm) {
+                            const int e = (mm * S + lo) * (N >> (3 * K + 1 + a));
+                            c[2 * (((1 << a) - 1) + mm)] = p.tw[2 * static_cast<size_t>(e)];
+                            c[2 * (((1 << a) - 1) + mm) + 1] = p.tw[2 * static_cast<size_t>(e) + 1];
+                        }
+                    uint32_t o[2] = {0, 0};  // a byte per output slot, 0xff = not needed
+                    for (int ri = 0; ri < 8; ++ri)
+                        o[ri >> 2] |= static_cast<uint32_t>(rank_in(Rout, ri * S + lo) & 0xff) << (8 * (ri & 3));
+                    std::memcpy(c + 14, o, 8);
+                }
+            };
+            classes(p.prune_t1, R3, pr.sh3, 1, R6);
+            classes(p.prune_t2, R6, pr.sh6, 2, R9);
+            for (int i = 0; i < nch; ++i)
+                p.prune_chan_rank[static_cast<size_t>(i)] = rank_in(R9, static_cast<int>(p.cp[static_cast<size_t>(i)].bin));
+            // it pays when the packed passes are well under the full ones: pass 1 shrinks to m3/8, pass 2 to m6/64
+            pr.enabled = (pr.m3 * 8 + pr.m6 <= 64 && pr.m9 < 255) ? 1 : 0;
         }
-        auto rank_of = [&](int s, int v) {
-            const std::vector<int>& r = R[static_cast<size_t>(s)];
-            return static_cast<int>(std::lower_bound(r.begin(), r.end(), v) - r.begin());
-        };
-        long nodes = 0;
-        int bufsz = 0;
-        for (int s = 3; s <= L; ++s) {
-            const int m = static_cast<int>(R[static_cast<size_t>(s)].size());
-            int sh = 0;
-            while ((1 << sh) < m)
-                ++sh;
-            pr.m[s] = m;
-            pr.sh[s] = sh;
-            bufsz = std::max(bufsz, (N >> s) * m);
-            if (s >= 4)
-                nodes += static_cast<long>(N >> s) * m;
-        }
-        for (int r = 0; r < 8; ++r)
-            pr.rank3[r] = std::binary_search(R[3].begin(), R[3].end(), r) ? rank_of(3, r) : -1;
-        for (int s = 4; s <= L; ++s) {
-            pr.ent_off[s] = static_cast<int32_t>(p.prune_entries.size() / 4);
-            const int h = 1 << (s - 1);
-            for (int v : R[static_cast<size_t>(s)]) {
-                const int lo = v & (h - 1);
-                const int e = lo * (N >> s);  // twiddle exponent of the butterfly, < N/2
-                const int32_t src = rank_of(s - 1, lo);
-                float bits;
-                std::memcpy(&bits, &src, 4);
-                p.prune_entries.push_back(p.tw[2 * static_cast<size_t>(e)]);
-                p.prune_entries.push_back(p.tw[2 * static_cast<size_t>(e) + 1]);
-                p.prune_entries.push_back(v >= h ? -1.0f : 1.0f);
-                p.prune_entries.push_back(bits);
-            }
-        }
-        for (int i = 0; i < nch; ++i)
-            p.prune_chan_rank[static_cast<size_t>(i)] = rank_of(L, static_cast<int>(p.cp[static_cast<size_t>(i)].bin));
-        pr.bufsz = (bufsz + 1) & ~1;  // (even: the slots of the node buffers stay 16-byte aligned)
-        pr.nentries = static_cast<int32_t>(p.prune_entries.size() / 4);
-        // worth it when the later stages shrink to well under half of the (L - 3) * N butterfly halves of the full graph;
-        // AFC walks the whole spectrum of a window, so those handles keep the full graph
-        pr.enabled = (!p.any_afc && nodes * 2 <= static_cast<long>(L - 3) * N) ? 1 : 0;
     }
     return MI_OK;
 }

@@ -44,21 +44,22 @@ struct ChanParams {
     uint32_t afc;       // channel_t.afc (0 = off .. 255), boondock_airband.h:258
 };
 
-// Pruning of the radix-2 DIT graph to the bins the channel plan picks (channelize.hip).  Stage s (blocks of 2^s) only has
-// to produce the residues R_s = { bin mod 2^s }; with m_s = |R_s| that is (N >> s) * m_s nodes instead of N.  Every node is
-// computed with the operations of the full graph, so the picked bins keep their bits.
-constexpr int kPruneMaxStage = 14;
+// Pruning of the radix-2 DIT graph to the bins the channel plan picks (channelize.hip, N = 512).  After the radix-8 pass
+// over stages 3K-2 .. 3K only the residues R_3K = { bin mod 8^K } of every block are needed, so the next pass has work for
+// m_3K of every 8^K lanes only: its work items (block, residue) are packed densely onto the lanes, several windows per
+// wave.  Every butterfly that is evaluated is the full graph's butterfly, so the picked bins keep their bits.
 struct PrunePlan {
-    int32_t enabled;                   // 0: evaluate the full graph
-    int32_t m[kPruneMaxStage];         // m_s for s = 3 .. log2n
-    int32_t sh[kPruneMaxStage];        // log2 of the next power of two >= m_s (lane mapping)
-    int32_t ent_off[kPruneMaxStage];   // first entry of stage s in `entries` (s >= 4)
-    int32_t rank3[8];                  // rank of residue r in R_3, or -1 when stage 3 need not keep it
-    int32_t bufsz;                     // largest node count of a stage (per FFT slot, float2)
-    int32_t nentries;
+    int32_t enabled;      // 0: evaluate the full graph
+    int32_t m3, sh3;      // |R_3| and log2 of the next power of two (items of pass 1 per window: 8 << sh3)
+    int32_t m6, sh6;      // |R_6|                                    (items of pass 2 per window: 1 << sh6)
+    int32_t m9;           // distinct picked bins
+    int32_t rs1, rs2;     // row strides (float2) of the two exchange buffers
+    int32_t rank3[8];     // rank of residue r in R_3, or -1 when pass 0 need not keep it
 };
-// entry of node residue j at stage s: twiddle (x, y), sign of the butterfly half (z = +1 / -1), rank of its source residue in
-// R_(s-1) (w, as int bits)
+// Per work-item class (j = index into R_3 for pass 1, into R_6 for pass 2), 24 floats: 7 twiddles (x, y) in the order of
+// Pass::run, 8 ints (as bits): where output ri of the radix-8 goes in the next buffer, or -1 when no picked bin needs it,
+// 2 unused.
+constexpr int kPruneClassWords = 24;
 
 struct Plan {
     mi_device_cfg dev{};
@@ -74,13 +75,15 @@ struct Plan {
     std::vector<float> window;        // fft_size
     std::vector<float> tw;            // fft_size/2 x {re, im}
     std::vector<float> levels;        // 256 (u8 or s8 LUT)
+    bool conv_arith = false;          // u8: n * rcp with one fma correction equals the LUT for all 256 values
     float sin_lut[257], cos_lut[257];
     float conv_scale = 0.f;           // 1.0f / fullscale (s16, f32)
     std::vector<ChanParams> cp;       // nch
     std::vector<float> ctcss_coeff;   // n_ctcss_rows x 2 x kMaxTones  (fast, slow)
-    PrunePlan prune{};                // stage-1 graph pruning (disabled when it would not pay, or with AFC)
-    std::vector<float> prune_entries; // 4 floats per entry
-    std::vector<int32_t> prune_chan_rank;  // per channel: rank of its bin in R_log2n
+    PrunePlan prune{};                // stage-1 graph pruning (N = 512, no AFC, and only where it pays)
+    std::vector<float> prune_t1;      // (1 << sh3) classes x kPruneClassWords
+    std::vector<float> prune_t2;      // (1 << sh6) classes x kPruneClassWords
+    std::vector<int32_t> prune_chan_rank;  // per channel: rank of its bin among the distinct picked bins
     float initial_noise_floor = 5.0f;
 };
 

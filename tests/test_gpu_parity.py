@@ -563,10 +563,11 @@ def test_checkpoint_between_overlapping_calls_and_timing_ages(pkg, monkeypatch):
     assert_same(rest_b[0][1].cpu().numpy(), rest_a[0][1].cpu().numpy(), "flags after restoring the checkpoint")
 
 
-def test_pruned_stage1_graph_keeps_every_bit(pkg, tmp_path):
-    """MI_AIRBAND_PRUNE=1: stage 1 evaluates only the nodes of the radix-2 graph that feed the picked bins (PrunePlan).  Any
-    subset of the graph is computed with the same operations, so audio and raw I/Q stay bit-exact; run in a fresh process
-    because the switch is read once."""
+def test_stage1_alternative_instantiations_keep_every_bit(pkg, tmp_path):
+    """By default stage 1 evaluates, at N = 512, only the nodes of the radix-2 graph that feed the picked bins (PrunePlan) and
+    converts u8 samples arithmetically; every other test here runs that way.  MI_AIRBAND_PRUNE=0 / MI_AIRBAND_CONV_LUT=1 select
+    the full graph and the level table: any subset of the graph is computed with the same operations and the conversion is
+    checked against the table value by value, so audio and raw I/Q stay bit-exact.  Fresh process: the switches are read once."""
     import subprocess
     import sys
     import os
@@ -580,7 +581,7 @@ def test_pruned_stage1_graph_keeps_every_bit(pkg, tmp_path):
         "pkg = load_package()\n"
         "for name in ('config2', 'config3'):\n"
         "    centre, chans = getattr(pkg, name + '_channels')()\n"
-        "    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=9 if name == 'config2' else 11)\n"
+        "    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=9)\n"
         "    nbat = 6\n"
         "    kw = {} if name == 'config2' else dict(amp_q8=1024, active=lambda k: k % 4 != 2)\n"
         "    iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=2, **kw)\n"
@@ -592,7 +593,7 @@ def test_pruned_stage1_graph_keeps_every_bit(pkg, tmp_path):
         "    for c, ch in enumerate(chans):\n"
         "        if ch.has_iq_outputs:\n"
         "            assert np.array_equal(iqo[0, c].reshape(-1), oiq[c]), (name, c)\n"
-        "print('pruned ok')\n")
-    env = dict(os.environ, MI_AIRBAND_PRUNE="1")
+        "print('stage1 ok')\n")
+    env = dict(os.environ, MI_AIRBAND_PRUNE="0", MI_AIRBAND_CONV_LUT="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0 and "pruned ok" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "stage1 ok" in r.stdout, r.stdout + r.stderr
