@@ -361,6 +361,364 @@ __device__ __forceinline__ float fast_atan2(const float y, const float x) {  // 
     return angle;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Steady-state blocks (one channel per wave).  While the squelch sits in CLOSED or in OPEN and no sample makes it want to
+// leave, a step is the same straight-line arithmetic every time: up to 64 steps are then taken at once, step m in lane m.
+// Whatever does not depend on the previous step (derotation, the FIR half of the biquads, magnitudes, discriminators,
+// divisions, the output gate) is evaluated once across the lanes; every recurrence (the moving averages, the biquad
+// feedback, AGC, de-emphasis) is a systolic chain: pass p shifts the chain registers one lane up (DPP wave_shr:1) and
+// applies the step, so lane m holds the value after step m from pass m+1 on -- the same IEEE operations in the same order
+// as the sample loop, on the same operands.  The first lane whose step would do anything else (pre/post filter crossing the
+// squelch level, low-signal count reaching the abort, an AGC clip) ends the block: the steps before it (rounded down to a
+// multiple of four, the I/O granule) are committed, and the sample loop takes over from the state they leave.
+// lane j <- lane j-1; a lane whose source lane does not exist or is switched off keeps `keep`
+__device__ __forceinline__ float shr1(const float v, const float keep) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+
+struct BlockIo {
+    float* magrow;
+    const float2* zrow;
+    float* wmain;
+    float* carry;
+    float2* iqo;
+    uint32_t n;
+};
+
+// Returns the number of steps committed (a multiple of 4, possibly 0: then nothing was changed).  kmax in [4, 64], a multiple
+// of 4, not past the end of the batch nor, for CTCSS channels, up to a detector window's last sample.
+__device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, const BlockIo& io, const uint32_t i0, const int kmax, bool& batch_open) {
+    ChanState& s = c.s;
+    const ChanParams& P = c.p;
+    const int lane = c.lane;
+    const bool act = lane < kmax;
+    const bool st_open = s.current_state == SQ_OPEN;
+    const float k99 = 0.99f, n99 = static_cast<float>(1.0 - static_cast<double>(0.99f));
+    const float k97 = 0.97f, n97 = static_cast<float>(1.0 - static_cast<double>(0.97f));
+    const unsigned long long actmask = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
+
+    // ---- inputs of the block ----
+    const float x = act ? io.magrow[kAgcExtra + i0 + lane] : 0.0f;  // wavein[j]
+    float ax = 0.0f;                                                  // wavein[j - AGC_EXTRA]
+    float2 z = make_float2(0.0f, 0.0f);
+    float rt = 0.0f;  // buffer_[buffer_tail_] as step m sees it
+    const bool lp = P.lowpass_enabled && io.zrow;
+    if (st_open) {
+        if (act) {
+            ax = io.magrow[i0 + lane];
+            if (io.zrow)
+                z = io.zrow[i0 + lane];
+        }
+        if (lp) {
+            int t = s.buffer_tail + 1 + lane;
+            t = t >= kSquelchRing ? t - kSquelchRing : t;
+            rt = c.ring[t];
+        }
+    }
+
+    // ---- Squelch::process_raw_sample: noise floor every 16th sample, pre-filter averages (squelch.cpp:195-246) ----
+    const float b = x * n99;
+    float nf = s.noise_floor, cap = s.moving_avg_cap;
+    float Fin = s.pre_full, Cin = s.pre_capped;
+    float F = 0.0f, C = 0.0f, NFv = nf, CAPv = cap;
+    int zero_from = 64;  // first step that cleared squelch_level_cache_
+    {
+        int L = 0;
+        int nb = (15 - static_cast<int>(s.sample_count & 15u)) & 15;  // first step whose sample_count_ is a multiple of 16
+        while (L < kmax) {
+            if (L == nb) {  // calculate_noise_floor with the averages step L-1 left, squelch.cpp:477-490
+                nf = nf * k97 + std_min(Cin, nf) * n97 + 1e-6f;
+                cap = P.using_manual_level ? P.manual_cap : P.cap_factor * nf;
+                zero_from = min(zero_from, L);
+                nb += 16;
+            }
+            const int E = min(nb, kmax);
+            if (lane >= L) {
+                NFv = nf;
+                CAPv = cap;
+                float Fp = Fin, Cp = Cin;
+                const bool xsat = x >= cap;
+                for (int p = L; p < E; ++p) {
+                    Fp = shr1(F, Fp);
+                    Cp = shr1(C, Cp);
+                    F = Fp * k99 + b;
+                    const float v = std_min(cap, Cp * k99 + b);
+                    C = (Cp >= cap && xsat) ? cap : v;
+                }
+            }
+            Fin = lane_read(F, E - 1);
+            Cin = lane_read(C, E - 1);
+            L = E;
+        }
+    }
+    // squelch_level() as step m evaluates it (cache and all, squelch.cpp:164-177)
+    uint32_t recent = s.recent_open_count;
+    int ev_lane = 64;  // CLOSED: first step that finds closed_sample_count_ == recent_sample_size_ (squelch.cpp:442-449)
+    if (!st_open) {
+        const int togo = static_cast<int>(kRecentSampleSize) - static_cast<int>(s.closed_sample_count);
+        ev_lane = togo < 0 ? 0 : (togo > 64 ? 64 : togo);
+        zero_from = min(zero_from, ev_lane);
+        if (lane >= ev_lane)
+            recent = 0;
+    }
+    float level;
+    if (P.using_manual_level) {
+        level = P.manual_signal_level;
+    } else {
+        const float ratio = (recent >= kFlapOpensThreshold && P.flappy_signal_ratio < P.normal_signal_ratio) ? P.flappy_signal_ratio : P.normal_signal_ratio;
+        level = (lane < zero_from && s.squelch_level_cache != 0.0f) ? s.squelch_level_cache : ratio * NFv;
+    }
+    const bool has_pre = C >= level;
+
+    if (!st_open) {
+        // ---- CLOSED: nothing else happens as long as the pre-filter average stays under the level ----
+        const unsigned long long failm = __ballot(has_pre) & actmask;
+        const int k = failm ? __builtin_ctzll(failm) : kmax;
+        const int kc = k & ~3;
+        if (kc == 0)
+            return 0;
+        const int last = kc - 1;
+        if (P.lowpass_enabled && lane < kc) {
+            int h = s.buffer_head + 1 + lane;
+            h = h >= kSquelchRing ? h - kSquelchRing : h;
+            c.ring[h] = C * 0.9f;
+        }
+        if (lane < kc) {
+            const uint32_t v = kAgcExtra + i0 + lane;
+            float* dst = (v < io.n) ? io.wmain + v : io.carry + (v - io.n);
+            *dst = 0.0f;
+            if (io.iqo)
+                io.iqo[i0 + lane] = make_float2(0.0f, 0.0f);
+        }
+        s.noise_floor = lane_read(NFv, last);
+        s.moving_avg_cap = lane_read(CAPv, last);
+        s.pre_full = lane_read(F, last);
+        s.pre_capped = lane_read(C, last);
+        if (P.using_manual_level) {
+            if (zero_from <= last)
+                s.squelch_level_cache = 0.0f;
+        } else {
+            s.squelch_level_cache = lane_read(level, last);
+        }
+        s.sample_count += static_cast<uint32_t>(kc);
+        if (ev_lane <= last)
+            s.recent_open_count = 0;
+        s.closed_sample_count = min(s.closed_sample_count + static_cast<uint32_t>(kc), kRecentSampleSize);
+        s.buffer_head = (s.buffer_head + kc) % kSquelchRing;
+        s.buffer_tail = (s.buffer_tail + kc) % kSquelchRing;
+        return kc;
+    }
+
+    // ---- OPEN ----
+    bool fail = !has_pre;  // OPEN && !has_signal() -> CLOSING
+    int lsc;               // low_signal_count_ after step m
+    {
+        const unsigned long long ge = __ballot(x >= level);
+        const unsigned long long below = ge & ((2ull << lane) - 1ull);
+        lsc = below ? lane - (63 - __builtin_clzll(below)) : s.low_signal_count + lane + 1;
+        fail = fail || lsc >= kLowSignalAbort;
+    }
+
+    // derotation, low-pass, magnitude (rtl_airband.cpp:532-552)
+    float re = z.x, im = z.y, xf = x;
+    float xr = 0.0f, xi = 0.0f;
+    float PF = 0.0f, PC = 0.0f;
+    if (io.zrow) {
+        const uint32_t phi = (s.dm_phi + static_cast<uint32_t>(lane) * P.dm_dphi) & 0xffffffu;
+        const uint32_t idx = phi >> 16;  // sincosf_lut, util.cpp:113-127
+        const float fract = static_cast<float>(phi & 0xffff) / 65536.0f;
+        float v1 = a.sin_lut[idx], v2 = a.sin_lut[idx + 1];
+        const float swf = v1 + (v2 - v1) * fract;
+        v1 = a.cos_lut[idx];
+        v2 = a.cos_lut[idx + 1];
+        const float cwf = v1 + (v2 - v1) * fract;
+        const float nswf = -swf;
+        float re_tmp = z.x * cwf - z.y * nswf;
+        float im_tmp = z.y * cwf + z.x * nswf;
+        if (P.lowpass_enabled) {  // LowpassFilter::apply, filters.cpp:146-163
+            xr = re_tmp / P.lowpass_gain;
+            xi = im_tmp / P.lowpass_gain;
+            const float xr1 = shr1(xr, s.lp_xr[2]), xi1 = shr1(xi, s.lp_xi[2]);
+            const float xr2 = shr1(xr1, s.lp_xr[1]), xi2 = shr1(xi1, s.lp_xi[1]);
+            const float Ar = (xr2 + xr) + (2.0f * xr1), Ai = (xi2 + xi) + (2.0f * xi1);
+            float Yr = 0.0f, Yi = 0.0f;
+            float R1 = s.lp_yr[2], I1 = s.lp_yi[2], R2 = s.lp_yr[1], I2 = s.lp_yi[1];
+            for (int p = 0; p < kmax; ++p) {
+                R2 = shr1(R1, R2);
+                I2 = shr1(I1, I2);
+                R1 = shr1(Yr, R1);
+                I1 = shr1(Yi, I1);
+                Yr = Ar + (P.lowpass_yc0 * R2) + (P.lowpass_yc1 * R1);
+                Yi = Ai + (P.lowpass_yc0 * I2) + (P.lowpass_yc1 * I1);
+            }
+            re_tmp = Yr;
+            im_tmp = Yi;
+        }
+        re = re_tmp;
+        im = im_tmp;
+        xf = sqrtf(re * re + im * im);
+        if (P.lowpass_enabled) {  // Squelch::process_filtered_sample, squelch.cpp:248-276 (state OPEN)
+            const float b2 = xf * n99;
+            const bool xsat = xf >= CAPv;
+            float PFp = s.post_full, PCp = s.post_capped;
+            for (int p = 0; p < kmax; ++p) {
+                PFp = shr1(PF, PFp);
+                PCp = shr1(PC, PCp);
+                PF = PFp * k99 + b2;
+                const float v = std_min(CAPv, PCp * k99 + b2);
+                PC = (PCp >= CAPv && xsat) ? CAPv : v;
+            }
+            fail = fail || !(PCp >= rt);  // has_post_filter_signal() in process_raw_sample of this step
+            fail = fail || PC < rt;       // this step would ask for CLOSED
+        }
+    }
+
+    // audio (rtl_airband.cpp:571-609)
+    float d;        // the sample handed to process_audio_sample
+    float G = 0.0f;  // agcavgfast after step m
+    if (P.modulation == MI_MOD_AM) {
+        const bool upd = xf > level;
+        const float bA = xf * 0.005f;
+        float Gp = s.agcavgfast;
+        for (int p = 0; p < kmax; ++p) {
+            Gp = shr1(G, Gp);
+            G = upd ? Gp * 0.995f + bA : Gp;
+        }
+        d = (ax - G) / (G * 1.5f);
+        fail = fail || fabsf(d) > 0.8f;  // the clip feeds back into the AGC: the sample loop takes that step
+    } else {
+        const float pr = shr1(re, s.pr), pj = shr1(im, s.pj);
+        float w;
+        if (!a.fm_quadri) {
+            const float nbj = -pj;  // polar_disc_fast: multiply(ar, aj, br, -bj)
+            const float cr = re * pr - im * nbj;
+            const float cj = im * pr + re * nbj;
+            w = static_cast<float>(static_cast<double>(fast_atan2(cj, cr)) * M_1_PI);
+        } else {
+            w = static_cast<float>(static_cast<double>((pr * im - re * pj) / (re * re + im * im + 1.0f)) * M_1_PI);
+        }
+        const float bN = w * 0.005f;
+        float Gp = s.agcavgfast;
+        for (int p = 0; p < kmax; ++p) {
+            Gp = shr1(G, Gp);
+            G = Gp * 0.995f + bN;
+        }
+        const float e = (w - G) * P.one_minus_alpha;
+        float D = 0.0f, Dp = s.prev_waveout;
+        for (int p = 0; p < kmax; ++p) {
+            Dp = shr1(D, Dp);
+            D = e + Dp * P.alpha;
+        }
+        d = D;
+    }
+
+    const unsigned long long failm = __ballot(fail) & actmask;
+    const int k = failm ? __builtin_ctzll(failm) : kmax;
+    const int kc = k & ~3;
+    if (kc == 0)
+        return 0;
+    const int last = kc - 1;
+
+    // output gate (rtl_airband.cpp:612-641); is_open() cannot change inside the block (no detector window ends in it)
+    const bool gate = !P.ctcss_enabled || (s.cs_enough ? (s.cs_has_tone != 0) : (s.cf_has_tone != 0));
+    float out = 0.0f;
+    if (gate) {
+        out = d;
+        if (P.notch_enabled) {  // NotchFilter::apply, filters.cpp:50-64
+            const float u1 = shr1(d, s.notch_x[2]);
+            const float u2 = shr1(u1, s.notch_x[1]);
+            const float B = P.notch_d0 * d - P.notch_d1 * u1 + P.notch_d0 * u2;
+            float Y = 0.0f, Y1 = s.notch_y[2], Y2 = s.notch_y[1];
+            for (int p = 0; p < kc; ++p) {
+                Y2 = shr1(Y1, Y2);
+                Y1 = shr1(Y, Y1);
+                Y = B + P.notch_d1 * Y1 - P.notch_d2 * Y2;
+            }
+            out = Y;
+            s.notch_x[0] = lane_read(d, last - 2);
+            s.notch_x[1] = lane_read(d, last - 1);
+            s.notch_x[2] = lane_read(d, last);
+            s.notch_y[0] = lane_read(Y, last - 2);
+            s.notch_y[1] = lane_read(Y, last - 1);
+            s.notch_y[2] = lane_read(Y, last);
+        }
+        out *= P.ampfactor;
+        if (out != out)
+            out = 0.0f;
+        else if (out > 1.0f)
+            out = 1.0f;
+        else if (out < -1.0f)
+            out = -1.0f;
+        batch_open = true;
+    }
+
+    // ---- commit the first kc steps ----
+    if (lane < kc) {
+        if (io.zrow)
+            io.magrow[kAgcExtra + i0 + lane] = xf;  // channel->wavein[j] is overwritten (rtl_airband.cpp:548)
+        if (lp) {
+            int h = s.buffer_head + 1 + lane;
+            h = h >= kSquelchRing ? h - kSquelchRing : h;
+            c.ring[h] = C * 0.9f;
+        }
+        const uint32_t v = kAgcExtra + i0 + lane;
+        float* dst = (v < io.n) ? io.wmain + v : io.carry + (v - io.n);
+        *dst = out;
+        if (io.iqo)
+            io.iqo[i0 + lane] = gate ? make_float2(re, im) : make_float2(0.0f, 0.0f);
+    }
+    if (P.ctcss_enabled) {  // Squelch::process_audio_sample -> CTCSS::process_audio_sample, no window ends here (ctcss.cpp:124-135)
+        for (int m = 0; m < kc; ++m) {
+            const float smp = lane_read(d, m);
+            const float q0 = c.gs_c * c.gs_q1 - c.gs_q2 + smp;
+            c.gs_q2 = c.gs_q1;
+            c.gs_q1 = q0;
+            if (!s.cs_enough) {
+                const float f0 = c.gf_c * c.gf_q1 - c.gf_q2 + smp;
+                c.gf_q2 = c.gf_q1;
+                c.gf_q1 = f0;
+            }
+        }
+        s.cs_count += kc;
+        if (!s.cs_enough)
+            s.cf_count += kc;
+    }
+    s.noise_floor = lane_read(NFv, last);
+    s.moving_avg_cap = lane_read(CAPv, last);
+    s.pre_full = lane_read(F, last);
+    s.pre_capped = lane_read(C, last);
+    if (P.using_manual_level) {
+        if (zero_from <= last)
+            s.squelch_level_cache = 0.0f;
+    } else {
+        s.squelch_level_cache = lane_read(level, last);
+    }
+    s.sample_count += static_cast<uint32_t>(kc);
+    s.low_signal_count = __builtin_amdgcn_readlane(lsc, last);
+    s.buffer_head = (s.buffer_head + kc) % kSquelchRing;
+    s.buffer_tail = (s.buffer_tail + kc) % kSquelchRing;
+    if (io.zrow) {
+        s.dm_phi = (s.dm_phi + static_cast<uint32_t>(kc) * P.dm_dphi) & 0xffffffu;
+        if (P.lowpass_enabled) {
+            s.lp_xr[0] = lane_read(xr, last - 2), s.lp_xi[0] = lane_read(xi, last - 2);
+            s.lp_xr[1] = lane_read(xr, last - 1), s.lp_xi[1] = lane_read(xi, last - 1);
+            s.lp_xr[2] = lane_read(xr, last), s.lp_xi[2] = lane_read(xi, last);
+            s.lp_yr[0] = lane_read(re, last - 2), s.lp_yi[0] = lane_read(im, last - 2);
+            s.lp_yr[1] = lane_read(re, last - 1), s.lp_yi[1] = lane_read(im, last - 1);
+            s.lp_yr[2] = lane_read(re, last), s.lp_yi[2] = lane_read(im, last);
+            s.post_full = lane_read(PF, last);
+            s.post_capped = lane_read(PC, last);
+        }
+    }
+    s.agcavgfast = lane_read(G, last);
+    if (P.modulation != MI_MOD_AM) {
+        s.pr = lane_read(re, last);
+        s.pj = lane_read(im, last);
+        s.prev_waveout = lane_read(d, last);
+    }
+    return kc;
+}
+
 // kUni: one channel per wave -- all 64 lanes run it in lockstep on the same values.  It is its own instantiation so that
 // the compiler's uniformity analysis sees a row that depends on blockIdx alone: the channel state then sits in scalar
 // registers where it can, the state machine's integer work runs on the scalar unit and its branches are scalar branches.
@@ -426,8 +784,53 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
     if (zrow)
         nz0 = zg[0], nz1 = zg[1];
 
+    const BlockIo bio{magrow, zrow, wmain, carry, iqo, n};
+    int skip = 0;  // groups to take one by one before the next steady block is tried
     {
         for (uint32_t gi = 0; gi < ngroups; ++gi) {
+          if constexpr (kUni) {
+              const int st = c.s.current_state;
+              const bool lpz = P.lowpass_enabled && zrow;
+              if (skip > 0) {
+                  --skip;
+              } else if (a.steady_blocks && st == c.s.next_state &&
+                         (st == SQ_CLOSED || (st == SQ_OPEN && c.s.using_post_filter == (lpz ? 1 : 0)))) {
+                  int kmax = min(64, static_cast<int>(ngroups - gi) * 4);
+                  kmax = min(kmax, kWaveBatch - static_cast<int>(in_batch));  // the batch flag is written at a batch's last step
+                  if (st == SQ_OPEN && P.ctcss_enabled) {  // a detector window's last sample is taken by the sample loop
+                      kmax = min(kmax, P.ctcss_slow_window - 1 - c.s.cs_count);
+                      if (!c.s.cs_enough)
+                          kmax = min(kmax, P.ctcss_fast_window - 1 - c.s.cf_count);
+                  }
+                  kmax &= ~3;
+                  if (kmax >= 8) {
+                      const int kc = steady_block(c, a, bio, gi * 4, kmax, batch_open);
+                      if (kc > 0) {
+                          in_batch += static_cast<uint32_t>(kc);
+                          if (in_batch == kWaveBatch) {
+                              a.axc[static_cast<size_t>(row) * a.axc_stride + batch] = batch_open ? MI_SIGNAL : MI_NO_SIGNAL;
+                              if (batch_open)
+                                  c.s.active_counter++;
+                              batch_open = false;
+                              in_batch = 0;
+                              batch++;
+                          }
+                          gi += static_cast<uint32_t>(kc / 4);
+                          if (gi < ngroups) {  // the groups fetched ahead are behind us now
+                              nx = xg[gi];
+                              na = ag[gi];
+                              if (zrow)
+                                  nz0 = zg[2 * gi], nz1 = zg[2 * gi + 1];
+                          }
+                          if (kc < 8)
+                              skip = 8;
+                          --gi;  // the loop increment
+                          continue;
+                      }
+                      skip = 4;
+                  }
+              }
+          }
           const uint32_t i0 = gi * 4;
           const float4 cx = nx, ca = na, cz0 = nz0, cz1 = nz1;
           {

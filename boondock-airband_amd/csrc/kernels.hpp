@@ -93,6 +93,7 @@ struct DemodArgs {
     mi_channel_stats* stats;   // [rows]
     int fm_quadri;
     int lanes_per_wave;
+    int steady_blocks;  // one channel per wave: take runs of steady CLOSED / OPEN steps 64 at a time (demod.hip)
 };
 
 // AFC::finalize for one batch (rtl_airband.cpp:224-249), one thread per (stream, channel)

@@ -162,6 +162,13 @@ bool conv_lut_forced() {  // MI_AIRBAND_CONV_LUT=1: keep the level table for u8 
     }();
     return on;
 }
+bool steady_blocks_wanted() {  // MI_AIRBAND_STEADY=0: the serial stage 2 takes every step in the sample loop (A/B, tests)
+    static const bool on = [] {
+        const char* e = std::getenv("MI_AIRBAND_STEADY");
+        return !(e && *e && std::atoi(e) == 0);
+    }();
+    return on;
+}
 bool prune_wanted() {
     static const bool on = [] {
         const char* e = std::getenv("MI_AIRBAND_PRUNE");
@@ -242,6 +249,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     da.stats = h->d_stats;
     da.fm_quadri = h->plan.dev.fm_quadri;
     da.lanes_per_wave = lanes_per_wave_for(h->rows);
+    da.steady_blocks = steady_blocks_wanted() ? 1 : 0;
 
     // the serial kernels expect the carried AGC_EXTRA samples of every row at the front of the planes they work on
     auto head_in_place = [&]() -> int {
