@@ -376,6 +376,20 @@ __device__ __forceinline__ float shr1(const float v, const float keep) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
 
+// std::min(cap, v) for finite operands, in one instruction (the compare-and-select form costs two)
+__device__ __forceinline__ float vmin(const float a, const float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// n passes of a chain, four per trip: a lane that has its final value keeps it under further passes, so rounding the count
+// up is harmless (the compiler does not unroll loops around cross-lane operations by itself)
+#define MI_PASSES(first, end, ...)                  \
+    for (int p_ = (first); p_ < (end); p_ += 4) {   \
+        __VA_ARGS__ __VA_ARGS__ __VA_ARGS__ __VA_ARGS__ \
+    }
+
 struct BlockIo {
     float* magrow;
     const float2* zrow;
@@ -383,11 +397,15 @@ struct BlockIo {
     float* carry;
     float2* iqo;
     uint32_t n;
+    // wavein of the 64 steps after the previous block, requested while that block ran (its first use is the block's first
+    // operation; everything else a block loads is needed late enough to hide behind the pre-filter chain)
+    float xpre;
+    uint32_t xpre_i0;
 };
 
 // Returns the number of steps committed (a multiple of 4, possibly 0: then nothing was changed).  kmax in [4, 64], a multiple
 // of 4, not past the end of the batch nor, for CTCSS channels, up to a detector window's last sample.
-__device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, const BlockIo& io, const uint32_t i0, const int kmax, bool& batch_open) {
+__device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo& io, const uint32_t i0, const int kmax, bool& batch_open) {
     ChanState& s = c.s;
     const ChanParams& P = c.p;
     const int lane = c.lane;
@@ -398,7 +416,14 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, const Bl
     const unsigned long long actmask = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
 
     // ---- inputs of the block ----
-    const float x = act ? io.magrow[kAgcExtra + i0 + lane] : 0.0f;  // wavein[j]
+    float x = 0.0f;  // wavein[j]
+    if (act)
+        x = (io.xpre_i0 == i0) ? io.xpre : io.magrow[kAgcExtra + i0 + lane];
+    {
+        const uint32_t ni = i0 + static_cast<uint32_t>(kmax);
+        io.xpre = (ni + lane < io.n) ? io.magrow[kAgcExtra + ni + lane] : 0.0f;
+        io.xpre_i0 = ni;
+    }
     float ax = 0.0f;                                                  // wavein[j - AGC_EXTRA]
     float2 z = make_float2(0.0f, 0.0f);
     float rt = 0.0f;  // buffer_[buffer_tail_] as step m sees it
@@ -437,14 +462,14 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, const Bl
                 NFv = nf;
                 CAPv = cap;
                 float Fp = Fin, Cp = Cin;
-                const bool xsat = x >= cap;
-                for (int p = L; p < E; ++p) {
+                const float capx = x >= cap ? cap : __builtin_inff();  // capped_ >= cap && sample >= cap
+                MI_PASSES(L, E, {
                     Fp = shr1(F, Fp);
                     Cp = shr1(C, Cp);
                     F = Fp * k99 + b;
-                    const float v = std_min(cap, Cp * k99 + b);
-                    C = (Cp >= cap && xsat) ? cap : v;
-                }
+                    const float v = vmin(cap, Cp * k99 + b);
+                    C = (Cp >= capx) ? cap : v;
+                })
             }
             Fin = lane_read(F, E - 1);
             Cin = lane_read(C, E - 1);
@@ -543,14 +568,14 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, const Bl
             const float Ar = (xr2 + xr) + (2.0f * xr1), Ai = (xi2 + xi) + (2.0f * xi1);
             float Yr = 0.0f, Yi = 0.0f;
             float R1 = s.lp_yr[2], I1 = s.lp_yi[2], R2 = s.lp_yr[1], I2 = s.lp_yi[1];
-            for (int p = 0; p < kmax; ++p) {
+            MI_PASSES(0, kmax, {
                 R2 = shr1(R1, R2);
                 I2 = shr1(I1, I2);
                 R1 = shr1(Yr, R1);
                 I1 = shr1(Yi, I1);
                 Yr = Ar + (P.lowpass_yc0 * R2) + (P.lowpass_yc1 * R1);
                 Yi = Ai + (P.lowpass_yc0 * I2) + (P.lowpass_yc1 * I1);
-            }
+            })
             re_tmp = Yr;
             im_tmp = Yi;
         }
@@ -559,15 +584,15 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, const Bl
         xf = sqrtf(re * re + im * im);
         if (P.lowpass_enabled) {  // Squelch::process_filtered_sample, squelch.cpp:248-276 (state OPEN)
             const float b2 = xf * n99;
-            const bool xsat = xf >= CAPv;
+            const float capx = xf >= CAPv ? CAPv : __builtin_inff();
             float PFp = s.post_full, PCp = s.post_capped;
-            for (int p = 0; p < kmax; ++p) {
+            MI_PASSES(0, kmax, {
                 PFp = shr1(PF, PFp);
                 PCp = shr1(PC, PCp);
                 PF = PFp * k99 + b2;
-                const float v = std_min(CAPv, PCp * k99 + b2);
-                PC = (PCp >= CAPv && xsat) ? CAPv : v;
-            }
+                const float v = vmin(CAPv, PCp * k99 + b2);
+                PC = (PCp >= capx) ? CAPv : v;
+            })
             fail = fail || !(PCp >= rt);  // has_post_filter_signal() in process_raw_sample of this step
             fail = fail || PC < rt;       // this step would ask for CLOSED
         }
@@ -580,10 +605,10 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, const Bl
         const bool upd = xf > level;
         const float bA = xf * 0.005f;
         float Gp = s.agcavgfast;
-        for (int p = 0; p < kmax; ++p) {
+        MI_PASSES(0, kmax, {
             Gp = shr1(G, Gp);
             G = upd ? Gp * 0.995f + bA : Gp;
-        }
+        })
         d = (ax - G) / (G * 1.5f);
         fail = fail || fabsf(d) > 0.8f;  // the clip feeds back into the AGC: the sample loop takes that step
     } else {
@@ -599,16 +624,16 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, const Bl
         }
         const float bN = w * 0.005f;
         float Gp = s.agcavgfast;
-        for (int p = 0; p < kmax; ++p) {
+        MI_PASSES(0, kmax, {
             Gp = shr1(G, Gp);
             G = Gp * 0.995f + bN;
-        }
+        })
         const float e = (w - G) * P.one_minus_alpha;
         float D = 0.0f, Dp = s.prev_waveout;
-        for (int p = 0; p < kmax; ++p) {
+        MI_PASSES(0, kmax, {
             Dp = shr1(D, Dp);
             D = e + Dp * P.alpha;
-        }
+        })
         d = D;
     }
 
@@ -629,11 +654,11 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, const Bl
             const float u2 = shr1(u1, s.notch_x[1]);
             const float B = P.notch_d0 * d - P.notch_d1 * u1 + P.notch_d0 * u2;
             float Y = 0.0f, Y1 = s.notch_y[2], Y2 = s.notch_y[1];
-            for (int p = 0; p < kc; ++p) {
+            MI_PASSES(0, kc, {
                 Y2 = shr1(Y1, Y2);
                 Y1 = shr1(Y, Y1);
                 Y = B + P.notch_d1 * Y1 - P.notch_d2 * Y2;
-            }
+            })
             out = Y;
             s.notch_x[0] = lane_read(d, last - 2);
             s.notch_x[1] = lane_read(d, last - 1);
@@ -784,7 +809,7 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
     if (zrow)
         nz0 = zg[0], nz1 = zg[1];
 
-    const BlockIo bio{magrow, zrow, wmain, carry, iqo, n};
+    BlockIo bio{magrow, zrow, wmain, carry, iqo, n, 0.0f, 0xffffffffu};
     int skip = 0;  // groups to take one by one before the next steady block is tried
     {
         for (uint32_t gi = 0; gi < ngroups; ++gi) {
