@@ -30,6 +30,7 @@ AGC_EXTRA = 100
 
 MOD_AM, MOD_NFM = 0, 1
 OPT_EARLY_INPUT = 1  # MI_OPT_EARLY_INPUT
+OPT_STEADY_BLOCKS = 2  # MI_OPT_STEADY_BLOCKS
 SFMT_U8, SFMT_S8, SFMT_S16, SFMT_F32 = 1, 2, 3, 4
 
 MI_OK, MI_ERR_INVALID, MI_ERR_NO_DEVICE, MI_ERR_NOMEM, MI_ERR_HIP, MI_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5

@@ -83,6 +83,7 @@ struct mi_demod {
     hipEvent_t ev_head = nullptr;        // ... and after the audio head of the call has been written
     float* d_mag_set[kSets] = {};  // d_mag aliases d_mag_set[cur]
     uint32_t head_off = 0;     // plane index where the AGC_EXTRA carried samples of every row live (0 after a serial call)
+    bool steady_blocks = true;  // MI_OPT_STEADY_BLOCKS
     bool early_input = false;  // MI_OPT_EARLY_INPUT: the IQ of a call is valid when the call is made
     bool chain_live = false;   // d_core_carry holds the chain state at the end of the previous call (it was time-parallel)
     hipStream_t seg_stream[kSegStreams] = {nullptr};  // the speculative segment passes (need core(i) only)
@@ -249,7 +250,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     da.stats = h->d_stats;
     da.fm_quadri = h->plan.dev.fm_quadri;
     da.lanes_per_wave = lanes_per_wave_for(h->rows);
-    da.steady_blocks = steady_blocks_wanted() ? 1 : 0;
+    da.steady_blocks = h->steady_blocks ? 1 : 0;
 
     // the serial kernels expect the carried AGC_EXTRA samples of every row at the front of the planes they work on
     auto head_in_place = [&]() -> int {
@@ -573,6 +574,7 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     mi_demod* h = new (std::nothrow) mi_demod();
     if (!h)
         return fail(MI_ERR_NOMEM, "host allocation failed");
+    h->steady_blocks = steady_blocks_wanted();
     const char* msg = "";
     int rc = mi::build_plan(*dev, chans, nch, h->plan, &msg);
     if (rc != MI_OK) {
@@ -1024,6 +1026,9 @@ int mi_demod_set_option(mi_demod* h, int option, int value) {
     switch (option) {
         case MI_OPT_EARLY_INPUT:
             h->early_input = value != 0;
+            return MI_OK;
+        case MI_OPT_STEADY_BLOCKS:
+            h->steady_blocks = value != 0;
             return MI_OK;
         default:
             return fail(MI_ERR_INVALID, "unknown option");

@@ -180,8 +180,11 @@ int mi_demod_kernel_time_prev(mi_demod* h, int age, int index, const char** name
  * them before the work queued earlier on `hip_stream` has finished, which lets stage 1 and the serial core chain of a call
  * overlap the segment / fix passes of the previous call (time-parallel path).  Outputs still complete in stream order.
  * The audio buffer of a call must then also be free when the call is made (no reader of an earlier result still pending on
- * another stream): when it is not the buffer of the previous call, the segment passes may write it early. */
-enum { MI_OPT_EARLY_INPUT = 1 };
+ * another stream): when it is not the buffer of the previous call, the segment passes may write it early.
+ * MI_OPT_STEADY_BLOCKS (default 1, or 0 when MI_AIRBAND_STEADY=0 is in the environment): the serial stage 2 takes runs
+ * of steps during which the squelch stays CLOSED or OPEN 64 at a time; 0 = every step in the sample loop.  Results are
+ * bit-identical either way (audio, flags, statistics, checkpoint state); the switch exists for measurements and tests. */
+enum { MI_OPT_EARLY_INPUT = 1, MI_OPT_STEADY_BLOCKS = 2 };
 int mi_demod_set_option(mi_demod* h, int option, int value);
 
 /* ---- host-only views of the derived plan (no GPU needed; used by the CPU test-suite) ---- */

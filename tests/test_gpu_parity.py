@@ -597,3 +597,81 @@ def test_stage1_alternative_instantiations_keep_every_bit(pkg, tmp_path):
     env = dict(os.environ, MI_AIRBAND_PRUNE="0", MI_AIRBAND_CONV_LUT="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "stage1 ok" in r.stdout, r.stdout + r.stderr
+
+
+def _channel_zoo(pkg):
+    """24 channels at fft 512 covering every branch of the serial stage 2: AM / NFM, with and without the low-pass, notch,
+    CTCSS (right tone, no tone), manual squelch level, raw-I/Q outputs, odd ampfactors and de-emphasis constants."""
+    centre = 120000000
+    kinds = [
+        dict(),
+        dict(bandwidth=8000),
+        dict(notch=1000.0),
+        dict(squelch_snr_db=6.0, has_iq_outputs=1),
+        dict(squelch_threshold_dbfs=-45),
+        dict(bandwidth=5000, notch=400.0, ampfactor=2.5),
+        dict(modulation=pkg.MOD_NFM),
+        dict(modulation=pkg.MOD_NFM, bandwidth=12500),
+        dict(modulation=pkg.MOD_NFM, bandwidth=12500, ctcss=100.0),
+        dict(modulation=pkg.MOD_NFM, bandwidth=12500, ctcss=123.0),
+        dict(modulation=pkg.MOD_NFM, bandwidth=8000, notch=100.0, tau=75, has_iq_outputs=1),
+        dict(modulation=pkg.MOD_NFM, squelch_snr_db=4.0, ampfactor=0.5),
+    ]
+    chans = []
+    for k in range(24):
+        f = centre - 1150000 + 25000 + k * 95000
+        chans.append(pkg.channel_cfg(f, **kinds[k % len(kinds)]))
+    return centre, chans
+
+
+def _zoo_capture(pkg, dev, centre, chans, nbat, seed):
+    """Carriers of very different strength (some under the squelch level, some flapping around it, some strong enough to
+    clip the AM AGC), gated with different phases and a short period so that every squelch transition happens many times; a
+    CTCSS channel gets a carrier without the tone, an NFM channel an AM carrier."""
+    carriers = []
+    amps = [3072, 700, 1500, 260, 5000, 400, 2048, 900]
+    for k, c in enumerate(chans):
+        if k % 5 == 4:
+            continue
+        kind = 0 if c.modulation == pkg.MOD_AM else (2 if c.ctcss_freq > 0 and k % 2 == 0 else 1)
+        if k == 6:
+            kind = 0
+        carriers.append((c.freq - centre, kind, amps[k % len(amps)], (k * 7919) % 1000))
+    n = bytes_for_batches(dev, nbat) // 2
+    cfg = pkg.iqgen_cfg(sample_rate=dev.sample_rate, seed=seed, gate_samples=dev.sample_rate // 5, carriers=carriers)
+    return pkg.iqgen_host(cfg, 0, 0, n)
+
+
+@pytest.mark.parametrize("seed", [0xA1B2C3D4, 77])
+def test_steady_blocks_same_bits_and_state(pkg, seed):
+    """The serial stage 2 takes steady CLOSED / OPEN runs 64 steps at a time (demod.hip, steady_block).  With the blocks on
+    and off the audio, the batch flags, the raw I/Q, the statistics and the complete checkpoint state are identical, call by
+    call, and equal to the oracle -- over a channel zoo and a capture that drive every way out of a block."""
+    centre, chans = _channel_zoo(pkg)
+    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=9)
+    nbat, per_call = 12, 4
+    iq = _zoo_capture(pkg, dev, centre, chans, nbat, seed)
+    res = {}
+    for steady in (1, 0):
+        d = pkg.Demod(dev, chans, max_batches=per_call)
+        d.set_option(pkg.OPT_STEADY_BLOCKS, steady)
+        outs = []
+        for call in range(nbat // per_call):
+            pos = (call * per_call * WAVE_BATCH) * d.hop_bytes if call == 0 else (call * per_call * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+            wo, axc, iqo, _ = d.process([iq[pos:]], per_call, want_iq=True)
+            outs.append((wo.copy(), axc.copy(), iqo.copy(), bytes(d.stats()), d.get_state().copy()))
+        d.close()
+        res[steady] = outs
+    for call, (a, b) in enumerate(zip(res[1], res[0])):
+        assert_same(a[0], b[0], f"audio, call {call}")
+        assert_same(a[1], b[1], f"flags, call {call}")
+        assert_same(a[2], b[2], f"raw I/Q, call {call}")
+        assert a[3] == b[3], f"statistics differ after call {call}"
+        assert_same(a[4], b[4], f"checkpoint state, call {call}")
+    nb, owo, oaxc, oiq = oracle_run(dev, chans, iq, nbat, want_iq=True)
+    wo = np.concatenate([o[0][:, :, :per_call * WAVE_BATCH] for o in res[1]], axis=2)
+    axc = np.concatenate([o[1] for o in res[1]], axis=2)
+    assert_same(axc[0], oaxc, "flags vs oracle")
+    assert_same(wo[0], owo, "audio vs oracle")
+    opened = [(axc[0, k] == ord("*")).any() for k in range(len(chans))]
+    assert sum(opened) >= 8 and not all(opened)
