@@ -403,14 +403,28 @@ struct BlockIo {
     uint32_t xpre_i0;
 };
 
-// Returns the number of steps committed (a multiple of 4, possibly 0: then nothing was changed).  kmax in [4, 64], a multiple
-// of 4, not past the end of the batch nor, for CTCSS channels, up to a detector window's last sample.
+// Returns the number of steps committed (a multiple of 4, possibly 0: then nothing was changed).  Call with current_state_
+// == next_state_.  kmax in [4, 64], a multiple of 4, not past the end of the batch; the caller also keeps it short of the
+// step that ends a CTCSS detector window and of the step whose delay_ count decides OPENING / CLOSING / LOW_SIGNAL_ABORT
+// (and, while OPENING, the block does not straddle delay_ == buffer_size_, where the post filter starts).
+//   CLOSED            averages + noise floor; ends when the pre-filter average reaches the level
+//   OPENING           the same + low-signal count; raw-I/Q channels filter; post filter once delay_ >= buffer_size_
+//   OPEN              + has_signal() must hold; audio
+//   CLOSING           as OPEN without the has_signal() test (it is only asked when the delay runs out)
+//   LOW_SIGNAL_ABORT  averages + noise floor only
 __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo& io, const uint32_t i0, const int kmax, bool& batch_open) {
     ChanState& s = c.s;
     const ChanParams& P = c.p;
     const int lane = c.lane;
     const bool act = lane < kmax;
-    const bool st_open = s.current_state == SQ_OPEN;
+    const int st = s.current_state;
+    const bool m_closed = st == SQ_CLOSED, m_open = st == SQ_OPEN, m_opening = st == SQ_OPENING, m_abort = st == SQ_LOW_SIGNAL_ABORT;
+    const bool do_lsc = !m_closed && !m_abort;           // the low-signal count runs (squelch.cpp:233-245)
+    const bool do_filter = do_lsc && io.zrow != nullptr;  // should_filter_sample() holds on every step
+    const bool lp = P.lowpass_enabled && io.zrow;
+    const bool do_post = lp && do_lsc && (!m_opening || s.delay + 1 >= kSquelchRing);  // process_filtered_sample gets past its early return
+    const bool post_init = do_post && m_opening && s.delay + 1 == kSquelchRing;         // ... and starts from buffer_[buffer_tail_]
+    const bool do_audio = m_open || st == SQ_CLOSING;     // should_process_audio()
     const float k99 = 0.99f, n99 = static_cast<float>(1.0 - static_cast<double>(0.99f));
     const float k97 = 0.97f, n97 = static_cast<float>(1.0 - static_cast<double>(0.97f));
     const unsigned long long actmask = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
@@ -424,21 +438,19 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
         io.xpre = (ni + lane < io.n) ? io.magrow[kAgcExtra + ni + lane] : 0.0f;
         io.xpre_i0 = ni;
     }
-    float ax = 0.0f;                                                  // wavein[j - AGC_EXTRA]
+    float ax = 0.0f;  // wavein[j - AGC_EXTRA]
     float2 z = make_float2(0.0f, 0.0f);
     float rt = 0.0f;  // buffer_[buffer_tail_] as step m sees it
-    const bool lp = P.lowpass_enabled && io.zrow;
-    if (st_open) {
-        if (act) {
+    if (act) {
+        if (do_audio)
             ax = io.magrow[i0 + lane];
-            if (io.zrow)
-                z = io.zrow[i0 + lane];
-        }
-        if (lp) {
-            int t = s.buffer_tail + 1 + lane;
-            t = t >= kSquelchRing ? t - kSquelchRing : t;
-            rt = c.ring[t];
-        }
+        if (do_filter)
+            z = io.zrow[i0 + lane];
+    }
+    if (do_post) {
+        int t = s.buffer_tail + 1 + lane;
+        t = t >= kSquelchRing ? t - kSquelchRing : t;
+        rt = c.ring[t];
     }
 
     // ---- Squelch::process_raw_sample: noise floor every 16th sample, pre-filter averages (squelch.cpp:195-246) ----
@@ -479,7 +491,7 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     // squelch_level() as step m evaluates it (cache and all, squelch.cpp:164-177)
     uint32_t recent = s.recent_open_count;
     int ev_lane = 64;  // CLOSED: first step that finds closed_sample_count_ == recent_sample_size_ (squelch.cpp:442-449)
-    if (!st_open) {
+    if (m_closed) {
         const int togo = static_cast<int>(kRecentSampleSize) - static_cast<int>(s.closed_sample_count);
         ev_lane = togo < 0 ? 0 : (togo > 64 ? 64 : togo);
         zero_from = min(zero_from, ev_lane);
@@ -493,51 +505,14 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
         const float ratio = (recent >= kFlapOpensThreshold && P.flappy_signal_ratio < P.normal_signal_ratio) ? P.flappy_signal_ratio : P.normal_signal_ratio;
         level = (lane < zero_from && s.squelch_level_cache != 0.0f) ? s.squelch_level_cache : ratio * NFv;
     }
+    // Does a step evaluate squelch_level() at all?  Everywhere except in LOW_SIGNAL_ABORT on a channel without raw I/Q, where
+    // the sample loop never asks should_filter_sample(): there the cache stays cleared after a noise-floor update.
+    const bool level_used = !(m_abort && io.zrow == nullptr);
     const bool has_pre = C >= level;
 
-    if (!st_open) {
-        // ---- CLOSED: nothing else happens as long as the pre-filter average stays under the level ----
-        const unsigned long long failm = __ballot(has_pre) & actmask;
-        const int k = failm ? __builtin_ctzll(failm) : kmax;
-        const int kc = k & ~3;
-        if (kc == 0)
-            return 0;
-        const int last = kc - 1;
-        if (P.lowpass_enabled && lane < kc) {
-            int h = s.buffer_head + 1 + lane;
-            h = h >= kSquelchRing ? h - kSquelchRing : h;
-            c.ring[h] = C * 0.9f;
-        }
-        if (lane < kc) {
-            const uint32_t v = kAgcExtra + i0 + lane;
-            float* dst = (v < io.n) ? io.wmain + v : io.carry + (v - io.n);
-            *dst = 0.0f;
-            if (io.iqo)
-                io.iqo[i0 + lane] = make_float2(0.0f, 0.0f);
-        }
-        s.noise_floor = lane_read(NFv, last);
-        s.moving_avg_cap = lane_read(CAPv, last);
-        s.pre_full = lane_read(F, last);
-        s.pre_capped = lane_read(C, last);
-        if (P.using_manual_level) {
-            if (zero_from <= last)
-                s.squelch_level_cache = 0.0f;
-        } else {
-            s.squelch_level_cache = lane_read(level, last);
-        }
-        s.sample_count += static_cast<uint32_t>(kc);
-        if (ev_lane <= last)
-            s.recent_open_count = 0;
-        s.closed_sample_count = min(s.closed_sample_count + static_cast<uint32_t>(kc), kRecentSampleSize);
-        s.buffer_head = (s.buffer_head + kc) % kSquelchRing;
-        s.buffer_tail = (s.buffer_tail + kc) % kSquelchRing;
-        return kc;
-    }
-
-    // ---- OPEN ----
-    bool fail = !has_pre;  // OPEN && !has_signal() -> CLOSING
-    int lsc;               // low_signal_count_ after step m
-    {
+    bool fail = m_closed ? has_pre : (m_open ? !has_pre : false);
+    int lsc = 0;  // low_signal_count_ after step m
+    if (do_lsc) {
         const unsigned long long ge = __ballot(x >= level);
         const unsigned long long below = ge & ((2ull << lane) - 1ull);
         lsc = below ? lane - (63 - __builtin_clzll(below)) : s.low_signal_count + lane + 1;
@@ -545,10 +520,10 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     }
 
     // derotation, low-pass, magnitude (rtl_airband.cpp:532-552)
-    float re = z.x, im = z.y, xf = x;
+    float re = 0.0f, im = 0.0f, xf = x;
     float xr = 0.0f, xi = 0.0f;
     float PF = 0.0f, PC = 0.0f;
-    if (io.zrow) {
+    if (do_filter) {
         const uint32_t phi = (s.dm_phi + static_cast<uint32_t>(lane) * P.dm_dphi) & 0xffffffu;
         const uint32_t idx = phi >> 16;  // sincosf_lut, util.cpp:113-127
         const float fract = static_cast<float>(phi & 0xffff) / 65536.0f;
@@ -582,10 +557,11 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
         re = re_tmp;
         im = im_tmp;
         xf = sqrtf(re * re + im * im);
-        if (P.lowpass_enabled) {  // Squelch::process_filtered_sample, squelch.cpp:248-276 (state OPEN)
+        if (do_post) {  // Squelch::process_filtered_sample, squelch.cpp:248-276
             const float b2 = xf * n99;
             const float capx = xf >= CAPv ? CAPv : __builtin_inff();
-            float PFp = s.post_full, PCp = s.post_capped;
+            const float rt0 = lane_read(rt, 0);
+            float PFp = post_init ? rt0 : s.post_full, PCp = post_init ? rt0 : s.post_capped;
             MI_PASSES(0, kmax, {
                 PFp = shr1(PF, PFp);
                 PCp = shr1(PC, PCp);
@@ -593,48 +569,51 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
                 const float v = vmin(CAPv, PCp * k99 + b2);
                 PC = (PCp >= capx) ? CAPv : v;
             })
-            fail = fail || !(PCp >= rt);  // has_post_filter_signal() in process_raw_sample of this step
-            fail = fail || PC < rt;       // this step would ask for CLOSED
+            if (m_open)
+                fail = fail || !(PCp >= rt);  // has_post_filter_signal() in process_raw_sample of this step
+            fail = fail || PC < rt;           // this step would ask for CLOSED
         }
     }
 
     // audio (rtl_airband.cpp:571-609)
-    float d;        // the sample handed to process_audio_sample
+    float d = 0.0f;  // the sample handed to process_audio_sample
     float G = 0.0f;  // agcavgfast after step m
-    if (P.modulation == MI_MOD_AM) {
-        const bool upd = xf > level;
-        const float bA = xf * 0.005f;
-        float Gp = s.agcavgfast;
-        MI_PASSES(0, kmax, {
-            Gp = shr1(G, Gp);
-            G = upd ? Gp * 0.995f + bA : Gp;
-        })
-        d = (ax - G) / (G * 1.5f);
-        fail = fail || fabsf(d) > 0.8f;  // the clip feeds back into the AGC: the sample loop takes that step
-    } else {
-        const float pr = shr1(re, s.pr), pj = shr1(im, s.pj);
-        float w;
-        if (!a.fm_quadri) {
-            const float nbj = -pj;  // polar_disc_fast: multiply(ar, aj, br, -bj)
-            const float cr = re * pr - im * nbj;
-            const float cj = im * pr + re * nbj;
-            w = static_cast<float>(static_cast<double>(fast_atan2(cj, cr)) * M_1_PI);
+    if (do_audio) {
+        if (P.modulation == MI_MOD_AM) {
+            const bool upd = xf > level;
+            const float bA = xf * 0.005f;
+            float Gp = s.agcavgfast;
+            MI_PASSES(0, kmax, {
+                Gp = shr1(G, Gp);
+                G = upd ? Gp * 0.995f + bA : Gp;
+            })
+            d = (ax - G) / (G * 1.5f);
+            fail = fail || fabsf(d) > 0.8f;  // the clip feeds back into the AGC: the sample loop takes that step
         } else {
-            w = static_cast<float>(static_cast<double>((pr * im - re * pj) / (re * re + im * im + 1.0f)) * M_1_PI);
+            const float pr = shr1(re, s.pr), pj = shr1(im, s.pj);
+            float w;
+            if (!a.fm_quadri) {
+                const float nbj = -pj;  // polar_disc_fast: multiply(ar, aj, br, -bj)
+                const float cr = re * pr - im * nbj;
+                const float cj = im * pr + re * nbj;
+                w = static_cast<float>(static_cast<double>(fast_atan2(cj, cr)) * M_1_PI);
+            } else {
+                w = static_cast<float>(static_cast<double>((pr * im - re * pj) / (re * re + im * im + 1.0f)) * M_1_PI);
+            }
+            const float bN = w * 0.005f;
+            float Gp = s.agcavgfast;
+            MI_PASSES(0, kmax, {
+                Gp = shr1(G, Gp);
+                G = Gp * 0.995f + bN;
+            })
+            const float e = (w - G) * P.one_minus_alpha;
+            float D = 0.0f, Dp = s.prev_waveout;
+            MI_PASSES(0, kmax, {
+                Dp = shr1(D, Dp);
+                D = e + Dp * P.alpha;
+            })
+            d = D;
         }
-        const float bN = w * 0.005f;
-        float Gp = s.agcavgfast;
-        MI_PASSES(0, kmax, {
-            Gp = shr1(G, Gp);
-            G = Gp * 0.995f + bN;
-        })
-        const float e = (w - G) * P.one_minus_alpha;
-        float D = 0.0f, Dp = s.prev_waveout;
-        MI_PASSES(0, kmax, {
-            Dp = shr1(D, Dp);
-            D = e + Dp * P.alpha;
-        })
-        d = D;
     }
 
     const unsigned long long failm = __ballot(fail) & actmask;
@@ -645,7 +624,7 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     const int last = kc - 1;
 
     // output gate (rtl_airband.cpp:612-641); is_open() cannot change inside the block (no detector window ends in it)
-    const bool gate = !P.ctcss_enabled || (s.cs_enough ? (s.cs_has_tone != 0) : (s.cf_has_tone != 0));
+    const bool gate = do_audio && (!P.ctcss_enabled || (s.cs_enough ? (s.cs_has_tone != 0) : (s.cf_has_tone != 0)));
     float out = 0.0f;
     if (gate) {
         out = d;
@@ -679,9 +658,9 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
 
     // ---- commit the first kc steps ----
     if (lane < kc) {
-        if (io.zrow)
+        if (do_filter)
             io.magrow[kAgcExtra + i0 + lane] = xf;  // channel->wavein[j] is overwritten (rtl_airband.cpp:548)
-        if (lp) {
+        if (P.lowpass_enabled) {
             int h = s.buffer_head + 1 + lane;
             h = h >= kSquelchRing ? h - kSquelchRing : h;
             c.ring[h] = C * 0.9f;
@@ -692,7 +671,7 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
         if (io.iqo)
             io.iqo[i0 + lane] = gate ? make_float2(re, im) : make_float2(0.0f, 0.0f);
     }
-    if (P.ctcss_enabled) {  // Squelch::process_audio_sample -> CTCSS::process_audio_sample, no window ends here (ctcss.cpp:124-135)
+    if (do_audio && P.ctcss_enabled) {  // Squelch::process_audio_sample -> CTCSS::process_audio_sample (ctcss.cpp:124-135)
         for (int m = 0; m < kc; ++m) {
             const float smp = lane_read(d, m);
             const float q0 = c.gs_c * c.gs_q1 - c.gs_q2 + smp;
@@ -712,17 +691,25 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     s.moving_avg_cap = lane_read(CAPv, last);
     s.pre_full = lane_read(F, last);
     s.pre_capped = lane_read(C, last);
-    if (P.using_manual_level) {
+    if (P.using_manual_level || !level_used) {
         if (zero_from <= last)
             s.squelch_level_cache = 0.0f;
     } else {
         s.squelch_level_cache = lane_read(level, last);
     }
     s.sample_count += static_cast<uint32_t>(kc);
-    s.low_signal_count = __builtin_amdgcn_readlane(lsc, last);
     s.buffer_head = (s.buffer_head + kc) % kSquelchRing;
     s.buffer_tail = (s.buffer_tail + kc) % kSquelchRing;
-    if (io.zrow) {
+    if (m_closed) {
+        if (ev_lane <= last)
+            s.recent_open_count = 0;
+        s.closed_sample_count = min(s.closed_sample_count + static_cast<uint32_t>(kc), kRecentSampleSize);
+    } else if (!m_open) {
+        s.delay += kc;
+    }
+    if (do_lsc)
+        s.low_signal_count = __builtin_amdgcn_readlane(lsc, last);
+    if (do_filter) {
         s.dm_phi = (s.dm_phi + static_cast<uint32_t>(kc) * P.dm_dphi) & 0xffffffu;
         if (P.lowpass_enabled) {
             s.lp_xr[0] = lane_read(xr, last - 2), s.lp_xi[0] = lane_read(xi, last - 2);
@@ -731,15 +718,20 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
             s.lp_yr[0] = lane_read(re, last - 2), s.lp_yi[0] = lane_read(im, last - 2);
             s.lp_yr[1] = lane_read(re, last - 1), s.lp_yi[1] = lane_read(im, last - 1);
             s.lp_yr[2] = lane_read(re, last), s.lp_yi[2] = lane_read(im, last);
+        }
+        if (do_post) {
             s.post_full = lane_read(PF, last);
             s.post_capped = lane_read(PC, last);
+            s.using_post_filter = 1;
         }
     }
-    s.agcavgfast = lane_read(G, last);
-    if (P.modulation != MI_MOD_AM) {
-        s.pr = lane_read(re, last);
-        s.pj = lane_read(im, last);
-        s.prev_waveout = lane_read(d, last);
+    if (do_audio) {
+        s.agcavgfast = lane_read(G, last);
+        if (P.modulation != MI_MOD_AM) {
+            s.pr = lane_read(re, last);
+            s.pj = lane_read(im, last);
+            s.prev_waveout = lane_read(d, last);
+        }
     }
     return kc;
 }
@@ -818,15 +810,32 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
               const bool lpz = P.lowpass_enabled && zrow;
               if (skip > 0) {
                   --skip;
-              } else if (a.steady_blocks && st == c.s.next_state &&
-                         (st == SQ_CLOSED || (st == SQ_OPEN && c.s.using_post_filter == (lpz ? 1 : 0)))) {
+              } else if (a.steady_blocks && st == c.s.next_state) {
                   int kmax = min(64, static_cast<int>(ngroups - gi) * 4);
                   kmax = min(kmax, kWaveBatch - static_cast<int>(in_batch));  // the batch flag is written at a batch's last step
-                  if (st == SQ_OPEN && P.ctcss_enabled) {  // a detector window's last sample is taken by the sample loop
-                      kmax = min(kmax, P.ctcss_slow_window - 1 - c.s.cs_count);
-                      if (!c.s.cs_enough)
-                          kmax = min(kmax, P.ctcss_fast_window - 1 - c.s.cf_count);
+                  bool ok = true;
+                  if (st == SQ_OPENING || st == SQ_CLOSING || st == SQ_LOW_SIGNAL_ABORT) {
+                      // the step whose delay_ reaches open_delay_ / close_delay_ decides: the sample loop takes it
+                      kmax = min(kmax, (st == SQ_OPENING ? kOpenDelay : kCloseDelay) - 1 - c.s.delay);
+                      if (st == SQ_OPENING && lpz) {
+                          if (c.s.delay + 1 < kSquelchRing) {  // process_filtered_sample still returns early ...
+                              kmax = min(kmax, kSquelchRing - 1 - c.s.delay);
+                              ok = c.s.using_post_filter == 0;
+                          } else {  // ... or runs on every step (it starts from buffer_[buffer_tail_] at delay_ == buffer_size_)
+                              ok = c.s.using_post_filter == (c.s.delay + 1 == kSquelchRing ? 0 : 1);
+                          }
+                      }
                   }
+                  if (st == SQ_OPEN || st == SQ_CLOSING) {
+                      ok = ok && c.s.using_post_filter == (lpz ? 1 : 0);
+                      if (P.ctcss_enabled) {  // a detector window's last sample is taken by the sample loop
+                          kmax = min(kmax, P.ctcss_slow_window - 1 - c.s.cs_count);
+                          if (!c.s.cs_enough)
+                              kmax = min(kmax, P.ctcss_fast_window - 1 - c.s.cf_count);
+                      }
+                  }
+                  if (!ok)
+                      kmax = 0;
                   kmax &= ~3;
                   if (kmax >= 8) {
                       const int kc = steady_block(c, a, bio, gi * 4, kmax, batch_open);
