@@ -376,21 +376,55 @@ __device__ __forceinline__ float shr1(const float v, const float keep) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
 
-// std::min(cap, v) for finite operands, in one instruction (the compare-and-select form costs two)
-__device__ __forceinline__ float vmin(const float a, const float b) {
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// n passes of a chain, four per trip: a lane that has its final value keeps it under further passes, so rounding the count
-// up is harmless (the compiler does not unroll loops around cross-lane operations by itself)
-#define MI_PASSES(first, end, ...)                  \
-    for (int p_ = (first); p_ < (end); p_ += 4) {   \
-        __VA_ARGS__ __VA_ARGS__ __VA_ARGS__ __VA_ARGS__ \
+// n passes of a chain, sixteen per trip: a lane that has its final value keeps it under further passes, so rounding the
+// count up is harmless.  (The compiler does not unroll loops around cross-lane operations by itself, and a taken branch
+// costs a lone wave about as much as a whole pass.)
+#define MI_PASSES4_(...) __VA_ARGS__ __VA_ARGS__ __VA_ARGS__ __VA_ARGS__
+#define MI_PASSES(first, end, ...)                   \
+    for (int p_ = (first); p_ < (end); p_ += 16) {   \
+        MI_PASSES4_(MI_PASSES4_(__VA_ARGS__))        \
     }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Four passes of the pair of moving averages of Squelch::update_moving_avg (squelch.cpp:501-514), lane m = step m:
+//   full   F[m] = F[m-1] * 0.99 + B[m]                                  (B = sample * (1 - 0.99))
+//   capped C[m] = C[m-1] >= CAPX[m] ? CAP[m] : min(CAP[m], C[m-1] * 0.99 + B[m])   (CAPX = CAP where sample >= CAP, else +inf)
+// T and P are only ever written through the shifted source, so lane 0, whose source does not exist, keeps what they were
+// preset to: full_ * 0.99 and capped_ of the state the block starts from.  The order keeps two instructions between a
+// write of F / C and its shifted read (the DPP hazard); the compare result goes through VCC, not an SGPR pair.
+#define MI_EMA_DPP " wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define MI_EMA_PASS                               \
+    "v_mul_f32_dpp %[T], %[F], %[K]" MI_EMA_DPP   \
+    "v_add_f32 %[F], %[T], %[B]\n"                \
+    "v_mov_b32_dpp %[P], %[C]" MI_EMA_DPP         \
+    "v_mul_f32 %[V], %[K], %[P]\n"                \
+    "v_cmp_ge_f32 vcc, %[P], %[CAPX]\n"           \
+    "v_add_f32 %[V], %[V], %[B]\n"                \
+    "v_min_f32 %[V], %[CAP], %[V]\n"              \
+    "v_cndmask_b32 %[C], %[V], %[CAP], vcc\n"
+#define MI_EMA_PASS4 MI_EMA_PASS MI_EMA_PASS MI_EMA_PASS MI_EMA_PASS
+__device__ __forceinline__ void ema_passes16(float& F, float& C, float& T, float& P, const float B, const float CAP, const float CAPX) {
+    const float K = 0.99f;
+    float V;
+    asm volatile("s_nop 1\n" MI_EMA_PASS4 MI_EMA_PASS4 MI_EMA_PASS4 MI_EMA_PASS4
+                 : [F] "+v"(F), [C] "+v"(C), [T] "+v"(T), [P] "+v"(P), [V] "=&v"(V)
+                 : [B] "v"(B), [CAP] "v"(CAP), [CAPX] "v"(CAPX), [K] "v"(K)
+                 : "vcc");
+}
+
+#ifdef MI_BLOCK_PROF
+#define MI_PROF_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); io.prof[k] += t_ - io.prof_t; io.prof_t = t_; } while (0)
+#else
+#define MI_PROF_MARK(k) do { } while (0)
+#endif
+
 struct BlockIo {
+#ifdef MI_BLOCK_PROF
+    unsigned long long prof[8];
+    unsigned long long prof_t;
+    unsigned long long blocks, steps;
+#endif
     float* magrow;
     const float2* zrow;
     float* wmain;
@@ -412,11 +446,13 @@ struct BlockIo {
 //   OPEN              + has_signal() must hold; audio
 //   CLOSING           as OPEN without the has_signal() test (it is only asked when the delay runs out)
 //   LOW_SIGNAL_ABORT  averages + noise floor only
-__device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo& io, const uint32_t i0, const int kmax, bool& batch_open) {
+__device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo& io, const uint32_t i0_, const int kmax_, bool& batch_open) {
+    // wave-uniform by construction; say so, so that loop control stays on the scalar unit
+    const uint32_t i0 = __builtin_amdgcn_readfirstlane(i0_);
+    const int kmax = __builtin_amdgcn_readfirstlane(kmax_);
     ChanState& s = c.s;
     const ChanParams& P = c.p;
     const int lane = c.lane;
-    const bool act = lane < kmax;
     const int st = s.current_state;
     const bool m_closed = st == SQ_CLOSED, m_open = st == SQ_OPEN, m_opening = st == SQ_OPENING, m_abort = st == SQ_LOW_SIGNAL_ABORT;
     const bool do_lsc = !m_closed && !m_abort;           // the low-signal count runs (squelch.cpp:233-245)
@@ -429,65 +465,69 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     const float k97 = 0.97f, n97 = static_cast<float>(1.0 - static_cast<double>(0.97f));
     const unsigned long long actmask = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
 
+#ifdef MI_BLOCK_PROF
+    io.prof_t = __builtin_readcyclecounter();
+    io.blocks++;
+#endif
     // ---- inputs of the block ----
-    float x = 0.0f;  // wavein[j]
-    if (act)
-        x = (io.xpre_i0 == i0) ? io.xpre : io.magrow[kAgcExtra + i0 + lane];
+    // wavein[j] was requested while the previous block ran (or is fetched now); its first use is the wait for it, and only
+    // then are the other loads issued -- the next block's samples, and what this block needs after the pre-filter chain --
+    // so that no wait in the chain has to cover a load that was issued a moment ago.
+    float x = io.xpre;  // arrived before the previous block's stores were issued (see the end of this function)
+    if (io.xpre_i0 != i0) {
+        x = io.magrow[kAgcExtra + min(i0 + static_cast<uint32_t>(lane), io.n - 1u)];
+        asm volatile("" : "+v"(x));  // the wait for this load stays inside the branch
+    }
+    const float b = x * n99;
+    __builtin_amdgcn_sched_barrier(0);
     {
         const uint32_t ni = i0 + static_cast<uint32_t>(kmax);
-        io.xpre = (ni + lane < io.n) ? io.magrow[kAgcExtra + ni + lane] : 0.0f;
+        const uint32_t idx = min(ni + static_cast<uint32_t>(lane), io.n - 1u);
+        io.xpre = io.magrow[kAgcExtra + idx];
         io.xpre_i0 = ni;
     }
-    float ax = 0.0f;  // wavein[j - AGC_EXTRA]
-    float2 z = make_float2(0.0f, 0.0f);
+    const uint32_t li = min(i0 + static_cast<uint32_t>(lane), io.n - 1u);  // lanes past kmax read a valid address, nobody uses the value
+    const float ax = io.magrow[li];  // wavein[j - AGC_EXTRA]
+    // (an unconditional load: a value that is merged with a constant at a join is waited for at the join)
+    const float2 z = (io.zrow ? io.zrow : reinterpret_cast<const float2*>(io.magrow))[io.zrow ? li : (li >> 1)];
     float rt = 0.0f;  // buffer_[buffer_tail_] as step m sees it
-    if (act) {
-        if (do_audio)
-            ax = io.magrow[i0 + lane];
-        if (do_filter)
-            z = io.zrow[i0 + lane];
-    }
     if (do_post) {
         int t = s.buffer_tail + 1 + lane;
         t = t >= kSquelchRing ? t - kSquelchRing : t;
         rt = c.ring[t];
     }
+    __builtin_amdgcn_sched_barrier(0);
+    MI_PROF_MARK(6);
 
     // ---- Squelch::process_raw_sample: noise floor every 16th sample, pre-filter averages (squelch.cpp:195-246) ----
-    const float b = x * n99;
     float nf = s.noise_floor, cap = s.moving_avg_cap;
-    float Fin = s.pre_full, Cin = s.pre_capped;
     float F = 0.0f, C = 0.0f, NFv = nf, CAPv = cap;
     int zero_from = 64;  // first step that cleared squelch_level_cache_
     {
+        // Every lane runs every pass with its own cap: the lanes before the current sixteen-step stretch have their final
+        // values and reproduce them, the first lane of the stretch finds its predecessor's final value one lane down.
+        float T = s.pre_full * k99, Pc = s.pre_capped;  // what lane 0 keeps reading (its shifted source does not exist)
+        float CAPX = __builtin_inff();                  // cap where sample >= cap, else +inf
         int L = 0;
-        int nb = (15 - static_cast<int>(s.sample_count & 15u)) & 15;  // first step whose sample_count_ is a multiple of 16
+        int nb = __builtin_amdgcn_readfirstlane((15 - static_cast<int>(s.sample_count & 15u)) & 15);  // first step whose sample_count_ is a multiple of 16
         while (L < kmax) {
             if (L == nb) {  // calculate_noise_floor with the averages step L-1 left, squelch.cpp:477-490
+                const float Cin = L ? lane_read(C, L - 1) : s.pre_capped;
                 nf = nf * k97 + std_min(Cin, nf) * n97 + 1e-6f;
                 cap = P.using_manual_level ? P.manual_cap : P.cap_factor * nf;
                 zero_from = min(zero_from, L);
                 nb += 16;
             }
             const int E = min(nb, kmax);
-            if (lane >= L) {
-                NFv = nf;
-                CAPv = cap;
-                float Fp = Fin, Cp = Cin;
-                const float capx = x >= cap ? cap : __builtin_inff();  // capped_ >= cap && sample >= cap
-                MI_PASSES(L, E, {
-                    Fp = shr1(F, Fp);
-                    Cp = shr1(C, Cp);
-                    F = Fp * k99 + b;
-                    const float v = vmin(cap, Cp * k99 + b);
-                    C = (Cp >= capx) ? cap : v;
-                })
-            }
-            Fin = lane_read(F, E - 1);
-            Cin = lane_read(C, E - 1);
+            const bool mine = lane >= L;
+            NFv = mine ? nf : NFv;
+            CAPv = mine ? cap : CAPv;
+            CAPX = mine ? (x >= cap ? cap : __builtin_inff()) : CAPX;
+            ema_passes16(F, C, T, Pc, b, CAPv, CAPX);  // a stretch is at most 16 steps; further passes change nothing
             L = E;
         }
     }
+    MI_PROF_MARK(0);
     // squelch_level() as step m evaluates it (cache and all, squelch.cpp:164-177)
     uint32_t recent = s.recent_open_count;
     int ev_lane = 64;  // CLOSED: first step that finds closed_sample_count_ == recent_sample_size_ (squelch.cpp:442-449)
@@ -519,6 +559,7 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
         fail = fail || lsc >= kLowSignalAbort;
     }
 
+    MI_PROF_MARK(1);
     // derotation, low-pass, magnitude (rtl_airband.cpp:532-552)
     float re = 0.0f, im = 0.0f, xf = x;
     float xr = 0.0f, xi = 0.0f;
@@ -540,41 +581,40 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
             xi = im_tmp / P.lowpass_gain;
             const float xr1 = shr1(xr, s.lp_xr[2]), xi1 = shr1(xi, s.lp_xi[2]);
             const float xr2 = shr1(xr1, s.lp_xr[1]), xi2 = shr1(xi1, s.lp_xi[1]);
-            const float Ar = (xr2 + xr) + (2.0f * xr1), Ai = (xi2 + xi) + (2.0f * xi1);
-            float Yr = 0.0f, Yi = 0.0f;
-            float R1 = s.lp_yr[2], I1 = s.lp_yi[2], R2 = s.lp_yr[1], I2 = s.lp_yi[1];
+            // (re, im) pairs: the feedback is two packed multiplies and two packed adds per pass
+            const v2f A = {(xr2 + xr) + (2.0f * xr1), (xi2 + xi) + (2.0f * xi1)};
+            const v2f c0 = {P.lowpass_yc0, P.lowpass_yc0}, c1 = {P.lowpass_yc1, P.lowpass_yc1};
+            v2f Y = {0.0f, 0.0f};
+            v2f Y1 = {s.lp_yr[2], s.lp_yi[2]}, Y2 = {s.lp_yr[1], s.lp_yi[1]};
             MI_PASSES(0, kmax, {
-                R2 = shr1(R1, R2);
-                I2 = shr1(I1, I2);
-                R1 = shr1(Yr, R1);
-                I1 = shr1(Yi, I1);
-                Yr = Ar + (P.lowpass_yc0 * R2) + (P.lowpass_yc1 * R1);
-                Yi = Ai + (P.lowpass_yc0 * I2) + (P.lowpass_yc1 * I1);
+                Y2.x = shr1(Y1.x, Y2.x);
+                Y2.y = shr1(Y1.y, Y2.y);
+                Y1.x = shr1(Y.x, Y1.x);
+                Y1.y = shr1(Y.y, Y1.y);
+                Y = (A + c0 * Y2) + c1 * Y1;
             })
+            const float Yr = Y.x, Yi = Y.y;
             re_tmp = Yr;
             im_tmp = Yi;
         }
         re = re_tmp;
         im = im_tmp;
         xf = sqrtf(re * re + im * im);
+        MI_PROF_MARK(2);
         if (do_post) {  // Squelch::process_filtered_sample, squelch.cpp:248-276
             const float b2 = xf * n99;
             const float capx = xf >= CAPv ? CAPv : __builtin_inff();
             const float rt0 = lane_read(rt, 0);
-            float PFp = post_init ? rt0 : s.post_full, PCp = post_init ? rt0 : s.post_capped;
-            MI_PASSES(0, kmax, {
-                PFp = shr1(PF, PFp);
-                PCp = shr1(PC, PCp);
-                PF = PFp * k99 + b2;
-                const float v = vmin(CAPv, PCp * k99 + b2);
-                PC = (PCp >= capx) ? CAPv : v;
-            })
+            float PT = (post_init ? rt0 : s.post_full) * k99, PCp = post_init ? rt0 : s.post_capped;
+            for (int p_ = 0; p_ < kmax; p_ += 16)
+                ema_passes16(PF, PC, PT, PCp, b2, CAPv, capx);
             if (m_open)
                 fail = fail || !(PCp >= rt);  // has_post_filter_signal() in process_raw_sample of this step
             fail = fail || PC < rt;           // this step would ask for CLOSED
         }
     }
 
+    MI_PROF_MARK(3);
     // audio (rtl_airband.cpp:571-609)
     float d = 0.0f;  // the sample handed to process_audio_sample
     float G = 0.0f;  // agcavgfast after step m
@@ -616,12 +656,19 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
         }
     }
 
+    MI_PROF_MARK(4);
+    // The next block's samples have long arrived: take them out of the memory counter now, before the stores below enter it
+    // (the counter is in order -- a wait for this load at the top of the next block would also wait for those stores).
+    asm volatile("" : "+v"(io.xpre));
     const unsigned long long failm = __ballot(fail) & actmask;
     const int k = failm ? __builtin_ctzll(failm) : kmax;
     const int kc = k & ~3;
     if (kc == 0)
         return 0;
     const int last = kc - 1;
+#ifdef MI_BLOCK_PROF
+    io.steps += kc;
+#endif
 
     // output gate (rtl_airband.cpp:612-641); is_open() cannot change inside the block (no detector window ends in it)
     const bool gate = do_audio && (!P.ctcss_enabled || (s.cs_enough ? (s.cs_has_tone != 0) : (s.cf_has_tone != 0)));
@@ -672,15 +719,19 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
             io.iqo[i0 + lane] = gate ? make_float2(re, im) : make_float2(0.0f, 0.0f);
     }
     if (do_audio && P.ctcss_enabled) {  // Squelch::process_audio_sample -> CTCSS::process_audio_sample (ctcss.cpp:124-135)
-        for (int m = 0; m < kc; ++m) {
-            const float smp = lane_read(d, m);
-            const float q0 = c.gs_c * c.gs_q1 - c.gs_q2 + smp;
-            c.gs_q2 = c.gs_q1;
-            c.gs_q1 = q0;
-            if (!s.cs_enough) {
-                const float f0 = c.gf_c * c.gf_q1 - c.gf_q2 + smp;
-                c.gf_q2 = c.gf_q1;
-                c.gf_q1 = f0;
+        const bool fast_too = !s.cs_enough;
+        for (int m = 0; m < kc; m += 4) {  // kc is a multiple of 4
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float smp = lane_read(d, m + u);
+                const float q0 = c.gs_c * c.gs_q1 - c.gs_q2 + smp;
+                c.gs_q2 = c.gs_q1;
+                c.gs_q1 = q0;
+                if (fast_too) {
+                    const float f0 = c.gf_c * c.gf_q1 - c.gf_q2 + smp;
+                    c.gf_q2 = c.gf_q1;
+                    c.gf_q1 = f0;
+                }
             }
         }
         s.cs_count += kc;
@@ -698,8 +749,8 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
         s.squelch_level_cache = lane_read(level, last);
     }
     s.sample_count += static_cast<uint32_t>(kc);
-    s.buffer_head = (s.buffer_head + kc) % kSquelchRing;
-    s.buffer_tail = (s.buffer_tail + kc) % kSquelchRing;
+    s.buffer_head = s.buffer_head + kc >= kSquelchRing ? s.buffer_head + kc - kSquelchRing : s.buffer_head + kc;
+    s.buffer_tail = s.buffer_tail + kc >= kSquelchRing ? s.buffer_tail + kc - kSquelchRing : s.buffer_tail + kc;
     if (m_closed) {
         if (ev_lane <= last)
             s.recent_open_count = 0;
@@ -733,6 +784,7 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
             s.prev_waveout = lane_read(d, last);
         }
     }
+    MI_PROF_MARK(5);
     return kc;
 }
 
@@ -801,7 +853,12 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
     if (zrow)
         nz0 = zg[0], nz1 = zg[1];
 
+#ifdef MI_BLOCK_PROF
+    BlockIo bio{{0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, magrow, zrow, wmain, carry, iqo, n, 0.0f, 0xffffffffu};
+    const unsigned long long prof_k0 = __builtin_readcyclecounter();
+#else
     BlockIo bio{magrow, zrow, wmain, carry, iqo, n, 0.0f, 0xffffffffu};
+#endif
     int skip = 0;  // groups to take one by one before the next steady block is tried
     {
         for (uint32_t gi = 0; gi < ngroups; ++gi) {
@@ -1093,6 +1150,11 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
         }
     }
 
+#ifdef MI_BLOCK_PROF
+    if (kUni && row == 0 && threadIdx.x == 0)
+        printf("blockprof row0: total %llu cyc, %llu blocks, %llu of %u steps in blocks; loads %llu prepass %llu pre %llu level+lsc %llu filter %llu post %llu audio %llu commit %llu\n",
+               __builtin_readcyclecounter() - prof_k0, bio.blocks, bio.steps, n, bio.prof[6], bio.prof[7], bio.prof[0], bio.prof[1], bio.prof[2], bio.prof[3], bio.prof[4], bio.prof[5]);
+#endif
     // plane carry: the last AGC_EXTRA (possibly low-pass-rewritten) magnitudes and raw bins move to the front,
     // the reference's memmove (rtl_airband.cpp:643-646)
     for (int v = 0; v < kAgcExtra; ++v)
