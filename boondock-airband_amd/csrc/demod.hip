@@ -466,7 +466,12 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     const unsigned long long actmask = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
 
 #ifdef MI_BLOCK_PROF
-    io.prof_t = __builtin_readcyclecounter();
+    {
+        const unsigned long long t_ = __builtin_readcyclecounter();
+        if (io.blocks)
+            io.prof[7] += t_ - io.prof_t;  // since the previous block returned
+        io.prof_t = t_;
+    }
     io.blocks++;
 #endif
     // ---- inputs of the block ----
@@ -860,35 +865,47 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
     BlockIo bio{magrow, zrow, wmain, carry, iqo, n, 0.0f, 0xffffffffu};
 #endif
     int skip = 0;  // groups to take one by one before the next steady block is tried
+    // After a block the group fetched ahead is not the next one.  It is fetched again only if the sample loop really takes
+    // the next group: a load into nx / na here would first wait for the previous load into the same registers, and that wait
+    // (the memory counter is in order) also covers the stores the block has just issued.
+    bool stale = false;
     {
         for (uint32_t gi = 0; gi < ngroups; ++gi) {
           if constexpr (kUni) {
-              const int st = c.s.current_state;
+              // wave-uniform by construction (one channel per wave): say so, so that this stays on the scalar unit
+              const int st = __builtin_amdgcn_readfirstlane(c.s.current_state);
+              const int nxt = __builtin_amdgcn_readfirstlane(c.s.next_state);
               const bool lpz = P.lowpass_enabled && zrow;
               if (skip > 0) {
                   --skip;
-              } else if (a.steady_blocks && st == c.s.next_state) {
+              } else if (a.steady_blocks && st == nxt) {
+                  const int delay = __builtin_amdgcn_readfirstlane(c.s.delay);
+                  const int upf = __builtin_amdgcn_readfirstlane(c.s.using_post_filter);
                   int kmax = min(64, static_cast<int>(ngroups - gi) * 4);
                   kmax = min(kmax, kWaveBatch - static_cast<int>(in_batch));  // the batch flag is written at a batch's last step
+                  // end on a multiple of 16 of sample_count_: the blocks after this one then see whole noise-floor periods
+                  const int phase = static_cast<int>((__builtin_amdgcn_readfirstlane(c.s.sample_count) + 1u) & 15u);
+                  if (phase && kmax == 64)
+                      kmax = 64 - phase;
                   bool ok = true;
                   if (st == SQ_OPENING || st == SQ_CLOSING || st == SQ_LOW_SIGNAL_ABORT) {
                       // the step whose delay_ reaches open_delay_ / close_delay_ decides: the sample loop takes it
-                      kmax = min(kmax, (st == SQ_OPENING ? kOpenDelay : kCloseDelay) - 1 - c.s.delay);
+                      kmax = min(kmax, (st == SQ_OPENING ? kOpenDelay : kCloseDelay) - 1 - delay);
                       if (st == SQ_OPENING && lpz) {
-                          if (c.s.delay + 1 < kSquelchRing) {  // process_filtered_sample still returns early ...
-                              kmax = min(kmax, kSquelchRing - 1 - c.s.delay);
-                              ok = c.s.using_post_filter == 0;
+                          if (delay + 1 < kSquelchRing) {  // process_filtered_sample still returns early ...
+                              kmax = min(kmax, kSquelchRing - 1 - delay);
+                              ok = upf == 0;
                           } else {  // ... or runs on every step (it starts from buffer_[buffer_tail_] at delay_ == buffer_size_)
-                              ok = c.s.using_post_filter == (c.s.delay + 1 == kSquelchRing ? 0 : 1);
+                              ok = upf == (delay + 1 == kSquelchRing ? 0 : 1);
                           }
                       }
                   }
                   if (st == SQ_OPEN || st == SQ_CLOSING) {
-                      ok = ok && c.s.using_post_filter == (lpz ? 1 : 0);
+                      ok = ok && upf == (lpz ? 1 : 0);
                       if (P.ctcss_enabled) {  // a detector window's last sample is taken by the sample loop
-                          kmax = min(kmax, P.ctcss_slow_window - 1 - c.s.cs_count);
+                          kmax = min(kmax, P.ctcss_slow_window - 1 - __builtin_amdgcn_readfirstlane(c.s.cs_count));
                           if (!c.s.cs_enough)
-                              kmax = min(kmax, P.ctcss_fast_window - 1 - c.s.cf_count);
+                              kmax = min(kmax, P.ctcss_fast_window - 1 - __builtin_amdgcn_readfirstlane(c.s.cf_count));
                       }
                   }
                   if (!ok)
@@ -907,12 +924,7 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
                               batch++;
                           }
                           gi += static_cast<uint32_t>(kc / 4);
-                          if (gi < ngroups) {  // the groups fetched ahead are behind us now
-                              nx = xg[gi];
-                              na = ag[gi];
-                              if (zrow)
-                                  nz0 = zg[2 * gi], nz1 = zg[2 * gi + 1];
-                          }
+                          stale = true;  // the group fetched ahead is behind us now
                           if (kc < 8)
                               skip = 8;
                           --gi;  // the loop increment
@@ -923,6 +935,13 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
               }
           }
           const uint32_t i0 = gi * 4;
+          if (stale) {
+              nx = xg[gi];
+              na = ag[gi];
+              if (zrow)
+                  nz0 = zg[2 * gi], nz1 = zg[2 * gi + 1];
+              stale = false;
+          }
           const float4 cx = nx, ca = na, cz0 = nz0, cz1 = nz1;
           {
               const uint32_t gn = (gi + 1 < ngroups) ? gi + 1 : gi;
@@ -1152,7 +1171,7 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
 
 #ifdef MI_BLOCK_PROF
     if (kUni && row == 0 && threadIdx.x == 0)
-        printf("blockprof row0: total %llu cyc, %llu blocks, %llu of %u steps in blocks; loads %llu prepass %llu pre %llu level+lsc %llu filter %llu post %llu audio %llu commit %llu\n",
+        printf("blockprof row0: total %llu cyc, %llu blocks, %llu of %u steps in blocks; loads %llu between blocks %llu pre %llu level+lsc %llu filter %llu post %llu audio %llu commit %llu\n",
                __builtin_readcyclecounter() - prof_k0, bio.blocks, bio.steps, n, bio.prof[6], bio.prof[7], bio.prof[0], bio.prof[1], bio.prof[2], bio.prof[3], bio.prof[4], bio.prof[5]);
 #endif
     // plane carry: the last AGC_EXTRA (possibly low-pass-rewritten) magnitudes and raw bins move to the front,
