@@ -191,7 +191,10 @@ __device__ __forceinline__ float nf_chain_min(const float nf, const float operan
     const float k97 = 0.97f, k03 = static_cast<float>(1.0 - static_cast<double>(0.97f));
     float v = nf, m, a = nf * k97, b;
     asm volatile("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(operand), "v"(nf));
-    for (int t = 0; t < passes; t += 4)
+    int t = 0;  // a taken branch costs a lone wave about as much as four passes: sixteen per trip while they last
+    for (; t + 16 <= passes; t += 16)
+        asm volatile(NF_X4(NF_X4(NF_PASS_MIN)) : "+v"(v), "+v"(m), "+v"(a), "=&v"(b) : "v"(operand), "v"(k97), "v"(k03));
+    for (; t < passes; t += 4)
         asm volatile(NF_X4(NF_PASS_MIN) : "+v"(v), "+v"(m), "+v"(a), "=&v"(b) : "v"(operand), "v"(k97), "v"(k03));
     return v;
 }
@@ -199,7 +202,10 @@ __device__ __forceinline__ float nf_chain_min(const float nf, const float operan
 __device__ __forceinline__ float nf_chain_self(const float nf, const int passes) {
     const float k97 = 0.97f, k03 = static_cast<float>(1.0 - static_cast<double>(0.97f));
     float v = nf, a = nf * k97, b = nf * k03;
-    for (int t = 0; t < passes; t += 4)
+    int t = 0;
+    for (; t + 16 <= passes; t += 16)
+        asm volatile(NF_X4(NF_X4(NF_PASS_SELF)) : "+v"(v), "+v"(a), "+v"(b) : "v"(k97), "v"(k03));
+    for (; t < passes; t += 4)
         asm volatile(NF_X4(NF_PASS_SELF) : "+v"(v), "+v"(a), "+v"(b) : "v"(k97), "v"(k03));
     return v;
 }
@@ -208,7 +214,10 @@ __device__ __forceinline__ float nf_chain_scaled(const float nf, const float sca
     const float k97 = 0.97f, k03 = static_cast<float>(1.0 - static_cast<double>(0.97f));
     float v = nf, a = nf * k97, m = nf * scale, b;
     asm volatile("v_min_f32 %0, %0, %1" : "+v"(m) : "v"(nf));
-    for (int t = 0; t < passes; t += 4)
+    int t = 0;
+    for (; t + 16 <= passes; t += 16)
+        asm volatile(NF_X4(NF_X4(NF_PASS_SCALED)) : "+v"(v), "+v"(m), "+v"(a), "=&v"(b) : "v"(scale), "v"(k97), "v"(k03));
+    for (; t < passes; t += 4)
         asm volatile(NF_X4(NF_PASS_SCALED) : "+v"(v), "+v"(m), "+v"(a), "=&v"(b) : "v"(scale), "v"(k97), "v"(k03));
     return v;
 }
