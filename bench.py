@@ -246,7 +246,8 @@ def main():
                 traffic[row["kernel"]] = int(row["hbm_bytes_per_launch"])
             traffic_src = f"profiles/{PMC_PROFILE}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command, FETCH_SIZE x2 (gfx950)"
         for name, k in kernels.items():
-            k["traffic"] = traffic.get(name.split("#")[0])
+            base = name.split("#")[0]
+            k["traffic"] = traffic.get(base, traffic.get(base + "9p"))  # k_channelize9p: the pruned N = 512 instantiation
         out = {
             "metric": f"IQ MS/s processed (x real-time) @ {nch}ch fft_size={1 << fft_log}",
             "value": value,

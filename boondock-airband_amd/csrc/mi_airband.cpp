@@ -75,7 +75,7 @@ struct mi_demod {
     int cur = 0;
     static constexpr int kSets = 3;  // a call writes the set of the call three back: by then that call has long finished
     hipEvent_t ev[kSets][3] = {};
-    static constexpr int kMaxChunks = 64, kEvPerChunk = 12, kSegStreams = 1;
+    static constexpr int kMaxChunks = 64, kEvPerChunk = 13, kSegStreams = 1;
     std::vector<hipEvent_t> chunk_ev[kSets];  // per chunk: stage1 begin/end, full end, core begin/end, seg begin/end, scan0/fix0/finish ends, rest begin
     hipStream_t aux_stream = nullptr;    // carries the serial core chain of the time-parallel path
     hipStream_t front_stream = nullptr;  // stage 1 + aggregates of the time-parallel path
@@ -420,21 +420,28 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             HIP_TRY(hipStreamWaitEvent(ss, ev(i, 4), 0));
             if (seg_early && h->set_seq[before_prev])  // the call before the previous one is complete (two audio buffers alternate)
                 HIP_TRY(hipStreamWaitEvent(ss, h->ev[before_prev][2], 0));
-            HIP_TRY(hipEventRecord(ev(i, 5), ss));
+            // (events 5 -> 12 time the pass itself: they sit inside every wait of the segment stream; of a split first chunk
+            // the body is timed, its few head segments are not)
             const uint32_t head_end = std::min<uint32_t>(c.seg1, mi::TP_W / mi::TP_L + 1);
             if (!seg_early || c.last_chunk) {
                 HIP_TRY(hipStreamWaitEvent(ss, h->ev_head, 0));
+                HIP_TRY(hipEventRecord(ev(i, 5), ss));
                 HIP_TRY(mi::launch_tp_seg(c, ss));
+                HIP_TRY(hipEventRecord(ev(i, 12), ss));
             } else if (c.first_chunk && c.seg0 < head_end) {
                 mi::TpArgs body = c, head = c;
                 body.seg0 = head_end;
                 head.seg1 = head_end;
+                HIP_TRY(hipEventRecord(ev(i, 5), ss));
                 if (body.seg0 < body.seg1)
                     HIP_TRY(mi::launch_tp_seg(body, ss));
+                HIP_TRY(hipEventRecord(ev(i, 12), ss));
                 HIP_TRY(hipStreamWaitEvent(ss, h->ev_head, 0));
                 HIP_TRY(mi::launch_tp_seg(head, ss));
             } else {
+                HIP_TRY(hipEventRecord(ev(i, 5), ss));
                 HIP_TRY(mi::launch_tp_seg(c, ss));
+                HIP_TRY(hipEventRecord(ev(i, 12), ss));
             }
             HIP_TRY(hipEventRecord(ev(i, 6), ss));
             HIP_TRY(hipStreamWaitEvent(s, ev(i, 6), 0));
@@ -963,9 +970,9 @@ static int kernel_time_of(mi_demod* h, int age, int index, const char** name, fl
         HIP_TRY(hipEventElapsedTime(&t, evq[index], evq[index + 1]));
     } else {
         // per chunk events: 0 stage1 begin, 1 stage1 end, 2 k_tp_full end (front stream), 3 core begin, 4 core end (aux stream),
-        // 5 seg begin, 6 seg end (segment stream), 10 scan#0 begin, 7 scan#0 end, 8 fix#0 + redo#0 end, 9 finish end (caller's stream), 11 k_tp_full begin
+        // 5 seg begin, 12 seg end, 6 all segment launches of the chunk done (segment stream), 10 scan#0 begin, 7 scan#0 end, 8 fix#0 + redo#0 end, 9 finish end (caller's stream), 11 k_tp_full begin
         static const char* const names[] = {"k_channelize", "k_tp_full", "k_tp_core", "k_tp_seg", "k_tp_scan#0", "k_tp_fix#0", "k_tp_rest"};
-        static const int from[] = {0, 11, 3, 5, 10, 7, 8}, to[] = {1, 2, 4, 6, 7, 8, 9};
+        static const int from[] = {0, 11, 3, 5, 10, 7, 8}, to[] = {1, 2, 4, 12, 7, 8, 9};
         if (index > 6)
             return fail(MI_ERR_INVALID, "kernel index out of range");
         nm = names[index];
