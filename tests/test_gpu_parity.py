@@ -675,3 +675,62 @@ def test_steady_blocks_same_bits_and_state(pkg, seed):
     assert_same(wo[0], owo, "audio vs oracle")
     opened = [(axc[0, k] == ord("*")).any() for k in range(len(chans))]
     assert sum(opened) >= 8 and not all(opened)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_steady_blocks_random_plans(pkg, seed):
+    """Random channel plans and captures (modulation, low-pass, notch, CTCSS, manual / SNR squelch thresholds down to 0 dB,
+    amplification, carriers from far under the squelch level to clipping, short gate periods): steady blocks on and off
+    leave the same audio, flags, raw I/Q and checkpoint state after every call.  (The oracle is not in this loop: both
+    sides are the product; the oracle comparison of the same code paths is test_steady_blocks_same_bits_and_state.)"""
+    rng = np.random.default_rng(seed)
+    centre = 120000000
+    nchan = 16
+    chans, carriers = [], []
+    for k in range(nchan):
+        f = centre - 1200000 + 40000 + k * 150000 + int(rng.integers(0, 20)) * 5000
+        kw = {}
+        nfm = rng.random() < 0.5
+        if nfm:
+            kw["modulation"] = pkg.MOD_NFM
+        if rng.random() < 0.5:
+            kw["bandwidth"] = int(rng.choice([5000, 8000, 12500]))
+        if rng.random() < 0.25:
+            kw["notch"] = float(rng.choice([100.0, 400.0, 1000.0]))
+        if nfm and rng.random() < 0.4:
+            kw["ctcss"] = float(rng.choice([100.0, 123.0, 151.4]))
+        r = rng.random()
+        if r < 0.2:
+            kw["squelch_threshold_dbfs"] = int(rng.integers(-55, -30))
+        elif r < 0.5:
+            kw["squelch_snr_db"] = float(rng.choice([0.0, 3.0, 6.0, 12.0]))
+        if rng.random() < 0.3:
+            kw["ampfactor"] = float(rng.choice([0.5, 2.0, 4.0]))
+        if rng.random() < 0.3:
+            kw["has_iq_outputs"] = 1
+        chans.append(pkg.channel_cfg(f, **kw))
+        if rng.random() < 0.8:
+            kind = int(rng.integers(0, 3))
+            carriers.append((f - centre, kind, int(rng.choice([150, 300, 600, 1200, 2500, 5000])), int(rng.integers(0, 1000))))
+    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=9, fm_quadri=int(seed % 2))
+    nbat, per_call = 8, 4
+    n = bytes_for_batches(dev, nbat) // 2
+    cfg = pkg.iqgen_cfg(sample_rate=dev.sample_rate, seed=1000 + seed, gate_samples=dev.sample_rate // int(rng.integers(3, 9)), carriers=carriers)
+    iq = pkg.iqgen_host(cfg, 0, 0, n)
+    res = {}
+    for steady in (1, 0):
+        d = pkg.Demod(dev, chans, max_batches=per_call)
+        d.set_option(pkg.OPT_STEADY_BLOCKS, steady)
+        outs = []
+        for call in range(nbat // per_call):
+            pos = 0 if call == 0 else (call * per_call * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+            wo, axc, iqo, _ = d.process([iq[pos:]], per_call, want_iq=True)
+            outs.append((wo.copy(), axc.copy(), iqo.copy(), bytes(d.stats()), d.get_state().copy()))
+        d.close()
+        res[steady] = outs
+    for call, (a, b) in enumerate(zip(res[1], res[0])):
+        assert_same(a[0], b[0], f"audio, call {call}")
+        assert_same(a[1], b[1], f"flags, call {call}")
+        assert_same(a[2], b[2], f"raw I/Q, call {call}")
+        assert a[3] == b[3], f"statistics differ after call {call}"
+        assert_same(a[4], b[4], f"checkpoint state, call {call}")

@@ -1,0 +1,13 @@
+"""One-off fuzz of the steady blocks: the randomized on/off comparison of tests/test_gpu_parity.py over many more seeds."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import conftest, test_gpu_parity as T
+pkg = conftest.load_package()
+bad = 0
+for seed in range(5, 65):
+    try:
+        T.test_steady_blocks_random_plans(pkg, seed)
+    except AssertionError as e:
+        bad += 1
+        print("seed", seed, "FAILED:", str(e)[:200])
+print("fuzz done, failures:", bad)
