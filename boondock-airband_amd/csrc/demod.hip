@@ -1176,12 +1176,17 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
 #endif
     // plane carry: the last AGC_EXTRA (possibly low-pass-rewritten) magnitudes and raw bins move to the front,
     // the reference's memmove (rtl_airband.cpp:643-646)
-    for (int v = 0; v < kAgcExtra; ++v)
-        magrow[v] = magrow[n + v];
-    if (zrow) {
-        float2* zw = a.cplx + (static_cast<size_t>(stream) * a.n_iq_rows + P.iq_row) * a.plane_stride;
+    {
+        float* __restrict__ hrow = a.mag_head + static_cast<size_t>(row) * a.plane_stride;
         for (int v = 0; v < kAgcExtra; ++v)
-            zw[v] = zw[n + v];
+            hrow[v] = magrow[n + v];
+    }
+    if (zrow) {
+        const size_t zoff = (static_cast<size_t>(stream) * a.n_iq_rows + P.iq_row) * a.plane_stride;
+        const float2* zw = a.cplx + zoff;
+        float2* zh = a.cplx_head + zoff;
+        for (int v = 0; v < kAgcExtra; ++v)
+            zh[v] = zw[n + v];
     }
 
     if (uni && P.ctcss_enabled) {

@@ -75,6 +75,8 @@ struct DemodArgs {
     uint32_t nbatches;
     float* mag;         // [rows][plane_stride]; index AGC_EXTRA+i is the squelch sample of step i
     float2* cplx;
+    float* mag_head;    // planes whose first AGC_EXTRA entries receive the carried samples at the end (the same planes, or
+    float2* cplx_head;  // the set the next call's stage 1 is already filling)
     size_t plane_stride;
     float* wmain;       // emitted audio, [rows][wmain_stride], nsteps valid
     size_t wmain_stride;

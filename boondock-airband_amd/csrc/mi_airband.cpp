@@ -74,7 +74,7 @@ struct mi_demod {
     // `cur` is the set of the last call; the serial path stays on it.
     int cur = 0;
     static constexpr int kSets = 3;  // a call writes the set of the call three back: by then that call has long finished
-    hipEvent_t ev[kSets][3] = {};
+    hipEvent_t ev[kSets][4] = {};  // per call: 0 begin, 1 stage 1 done, 2 call done, 3 serial k_demod begins (pipelined serial calls)
     static constexpr int kMaxChunks = 64, kEvPerChunk = 13, kSegStreams = 1;
     std::vector<hipEvent_t> chunk_ev[kSets];  // per chunk: stage1 begin/end, full end, core begin/end, seg begin/end, scan0/fix0/finish ends, rest begin
     hipStream_t aux_stream = nullptr;    // carries the serial core chain of the time-parallel path
@@ -82,6 +82,11 @@ struct mi_demod {
     hipEvent_t ev_entry = nullptr;       // recorded on the caller's stream when a call starts
     hipEvent_t ev_head = nullptr;        // ... and after the audio head of the call has been written
     float* d_mag_set[kSets] = {};  // d_mag aliases d_mag_set[cur]
+    float2* d_cplx_set[2] = {};    // pipelined serial calls alternate two plane sets (d_mag_set[0 / 1], d_cplx_set[0 / 1])
+    int pset = 0;                  // ... the one holding the carried head
+    bool serial_pipe = false;      // the last call was a pipelined serial call
+    float* d_mag_last = nullptr;   // ... and these are the planes it worked on (mi_demod_read_planes)
+    float2* d_cplx_last = nullptr;
     uint32_t head_off = 0;     // plane index where the AGC_EXTRA carried samples of every row live (0 after a serial call)
     bool steady_blocks = true;  // MI_OPT_STEADY_BLOCKS
     bool early_input = false;  // MI_OPT_EARLY_INPUT: the IQ of a call is valid when the call is made
@@ -193,6 +198,33 @@ int lanes_per_wave_for(int rows) {
 }
 
 // shared by both entry points; everything is enqueued on `s`
+// the second plane set of the pipelined serial path, allocated the first time it is wanted
+bool serial_sets_ready(mi_demod* h) {
+    if (h->d_mag_set[1] && (h->d_cplx_set[1] || !h->d_cplx_set[0]))
+        return true;
+    const size_t rows = static_cast<size_t>(h->rows);
+    if (!h->d_mag_set[1]) {
+        float* m = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&m), rows * h->plane_stride * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        (void)hipMemset(m, 0, rows * h->plane_stride * 4);
+        h->d_mag_set[1] = m;
+    }
+    if (h->d_cplx_set[0] && !h->d_cplx_set[1]) {
+        const size_t zn = static_cast<size_t>(h->nstreams) * h->plan.n_iq_rows * h->plane_stride;
+        float2* z = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&z), zn * 8) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        (void)hipMemset(z, 0, zn * 8);
+        h->d_cplx_set[1] = z;
+    }
+    return true;
+}
+
 int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t valid_bytes, int nbatches, float* d_wmain, size_t wmain_stride,
             float2* d_iq_out, size_t iq_out_stride, char* d_axc, hipStream_t s) {
     const int nfft = n_fft_for(h, nbatches);
@@ -232,6 +264,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     da.nbatches = static_cast<uint32_t>(nbatches);
     da.mag = h->d_mag;
     da.cplx = h->d_cplx;
+    da.mag_head = h->d_mag;
+    da.cplx_head = h->d_cplx;
     da.plane_stride = h->plane_stride;
     da.wmain = d_wmain;
     da.wmain_stride = wmain_stride;
@@ -260,7 +294,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         }
         return MI_OK;
     };
-    hipEvent_t* evc = h->ev[h->cur];  // (the time-parallel branch switches to the other set)
+    hipEvent_t* evc = h->ev[h->cur];  // (the time-parallel and the pipelined serial branch switch to the next set)
+    bool pipelined_serial = false;
     if (use_tp) {
         // ---- time-parallel stage 2, pipelined over chunks of the call and across calls ----
         // The exact core chain (k_tp_core) is serial per channel and latency bound on 8 waves; everything else is wide.
@@ -494,11 +529,48 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             HIP_TRY(mi::launch_afc(aa, s));
             f0 += nf;
         }
+    } else if (h->early_input && !h->tp_eligible && !h->first_call && serial_sets_ready(h)) {
+        // ---- serial stage 2 with consecutive calls overlapping (MI_OPT_EARLY_INPUT) ----
+        // Two plane sets alternate.  Stage 1 of this call fills the body of set p on the front stream while the previous
+        // call's k_demod, which reads the other set, still runs on the caller's stream (all that k_demod writes into set p
+        // is the carried head, entries [0, AGC_EXTRA), which stage 1 does not touch).  k_demod of this call waits for its
+        // stage 1 and leaves the head in the other set for the next call.
+        const int q = (h->cur + 1) % mi_demod::kSets;  // event / timing set of this call
+        const int before_prev = (h->cur + mi_demod::kSets - 1) % mi_demod::kSets;
+        const int p = h->pset, np = p ^ 1;
+        evc = h->ev[q];
+        hipStream_t fs = h->front_stream;
+        if (h->serial_pipe && h->set_seq[before_prev])  // the call before the previous one read the body of set p
+            HIP_TRY(hipStreamWaitEvent(fs, h->ev[before_prev][2], 0));
+        else
+            HIP_TRY(hipStreamWaitEvent(fs, h->ev[h->cur][2], 0));  // (first pipelined call: everything before it)
+        ca.mag = h->d_mag_set[p];
+        ca.cplx = h->d_cplx_set[p];
+        HIP_TRY(hipEventRecord(evc[0], fs));
+        HIP_TRY(mi::launch_channelize(ca, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, fs));
+        HIP_TRY(hipEventRecord(evc[1], fs));
+        HIP_TRY(hipStreamWaitEvent(s, evc[1], 0));
+        da.mag = h->d_mag_set[p];
+        da.cplx = h->d_cplx_set[p];
+        da.mag_head = h->d_mag_set[np];
+        da.cplx_head = h->d_cplx_set[np];
+        HIP_TRY(hipEventRecord(evc[3], s));
+        HIP_TRY(mi::launch_demod(da, s));
+        h->chain_live = false;
+        h->cur = q;
+        h->pset = np;
+        h->d_mag = h->d_mag_set[np];
+        h->d_cplx = h->d_cplx_set[np];
+        h->d_mag_last = h->d_mag_set[p];
+        h->d_cplx_last = h->d_cplx_set[p];
+        h->serial_pipe = true;
+        pipelined_serial = true;
     } else {
         int rc = head_in_place();
         if (rc != MI_OK)
             return rc;
         h->chain_live = false;  // k_demod does not maintain the time-parallel chain state
+        h->serial_pipe = false;
         HIP_TRY(hipEventRecord(evc[0], s));
         HIP_TRY(mi::launch_channelize(ca, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, s));
         HIP_TRY(hipEventRecord(evc[1], s));
@@ -507,7 +579,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     h->last_path = use_tp ? 1 : 0;
     HIP_TRY(hipEventRecord(evc[2], s));
     h->set_seq[h->cur] = ++h->call_seq;
-    h->set_path[h->cur] = h->last_path;
+    h->set_path[h->cur] = pipelined_serial ? 2 : h->last_path;
     h->first_call = false;
     return MI_OK;
 }
@@ -532,7 +604,7 @@ void mi_demod_destroy(mi_demod* h) {
         return;
     (void)hipSetDevice(h->gpu);
     (void)hipDeviceSynchronize();  // calls may still be in flight on the handle's own streams
-    void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_t1, h->d_prune_t2, h->d_prune_rank, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx, h->d_carry,
+    void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_t1, h->d_prune_t2, h->d_prune_rank, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx_set[0], h->d_cplx_set[1], h->d_carry,
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc,
                     h->d_rows,   h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_fullbound, h->d_afc_spec};
     for (void* p : ptrs)
@@ -649,6 +721,7 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     TRY_OR_BAIL(dalloc(&h->d_mag_set[0], rows * h->plane_stride));
     h->d_mag = h->d_mag_set[0];
     TRY_OR_BAIL(dalloc(&h->d_cplx, static_cast<size_t>(nstreams) * p.n_iq_rows * h->plane_stride));
+    h->d_cplx_set[0] = h->d_cplx;
     TRY_OR_BAIL(dalloc(&h->d_carry, rows * mi::kAgcExtra));
     TRY_OR_BAIL(dalloc(&h->d_ring, rows * mi::kSquelchRing));
     TRY_OR_BAIL(dalloc(&h->d_ctcss_coeff, p.ctcss_coeff.size()));
@@ -783,7 +856,11 @@ int mi_demod_process(mi_demod* h, const uint8_t* const* iq, int nbatches, float*
         std::memcpy(h->h_pin + static_cast<size_t>(i) * h->iq_stride, iq[i], need);
     }
     HIP_TRY(hipMemcpyAsync(h->d_iq, h->h_pin, h->iq_stride * (h->nstreams - 1) + need, hipMemcpyHostToDevice, s));
+    // the staging copy above is in stream order: MI_OPT_EARLY_INPUT (the IQ is valid when the call is made) does not hold here
+    const bool early = h->early_input;
+    h->early_input = false;
     int rc = enqueue(h, h->d_iq, h->iq_stride, need, nbatches, h->d_wout, nsteps, iq_out ? h->d_iqout : nullptr, nsteps, h->d_axc, s);
+    h->early_input = early;
     if (rc != MI_OK)
         return rc;
     // host layout: [rows][nsteps + AGC_EXTRA] = emitted audio followed by the lookahead (channel_t.waveout)
@@ -941,11 +1018,13 @@ int mi_demod_read_planes(mi_demod* h, int stream, int ch, int first, int count, 
     HIP_TRY(hipSetDevice(h->gpu));
     HIP_TRY(hipDeviceSynchronize());
     const size_t row = static_cast<size_t>(stream) * h->nch + ch;
-    HIP_TRY(hipMemcpy(mag, h->d_mag + row * h->plane_stride + first, static_cast<size_t>(count) * 4, hipMemcpyDeviceToHost));
+    const float* pm = h->serial_pipe ? h->d_mag_last : h->d_mag;  // (a pipelined serial call leaves d_mag on the set with the next head)
+    const float2* pz = h->serial_pipe ? h->d_cplx_last : h->d_cplx;
+    HIP_TRY(hipMemcpy(mag, pm + row * h->plane_stride + first, static_cast<size_t>(count) * 4, hipMemcpyDeviceToHost));
     const int iq_row = h->plan.cp[ch].iq_row;
     if (iq && iq_row >= 0) {
         const size_t zrow = static_cast<size_t>(stream) * h->plan.n_iq_rows + iq_row;
-        HIP_TRY(hipMemcpy(iq, h->d_cplx + zrow * h->plane_stride + first, static_cast<size_t>(count) * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(iq, pz + zrow * h->plane_stride + first, static_cast<size_t>(count) * 8, hipMemcpyDeviceToHost));
     }
     return MI_OK;
 }
@@ -963,11 +1042,14 @@ static int kernel_time_of(mi_demod* h, int age, int index, const char** name, fl
     float t = 0.f;
     int n = 1;
     const char* nm = nullptr;
-    if (h->set_path[q] == 0) {
+    if (h->set_path[q] == 0 || h->set_path[q] == 2) {
         if (index > 1)
             return fail(MI_ERR_INVALID, "kernel index out of range");
         nm = index == 0 ? "k_channelize" : "k_demod";
-        HIP_TRY(hipEventElapsedTime(&t, evq[index], evq[index + 1]));
+        if (h->set_path[q] == 2 && index == 1)  // pipelined serial call: k_demod starts at its own event on the caller's stream
+            HIP_TRY(hipEventElapsedTime(&t, evq[3], evq[2]));
+        else
+            HIP_TRY(hipEventElapsedTime(&t, evq[index], evq[index + 1]));
     } else {
         // per chunk events: 0 stage1 begin, 1 stage1 end, 2 k_tp_full end (front stream), 3 core begin, 4 core end (aux stream),
         // 5 seg begin, 12 seg end, 6 all segment launches of the chunk done (segment stream), 10 scan#0 begin, 7 scan#0 end, 8 fix#0 + redo#0 end, 9 finish end (caller's stream), 11 k_tp_full begin
@@ -1011,7 +1093,7 @@ int mi_demod_last_kernel_ms(mi_demod* h, float* channelize_ms, float* demod_ms) 
     float a = 0.f, b = 0.f;
     if (h->last_path == 0) {
         HIP_TRY(hipEventElapsedTime(&a, evq[0], evq[1]));
-        HIP_TRY(hipEventElapsedTime(&b, evq[1], evq[2]));
+        HIP_TRY(hipEventElapsedTime(&b, evq[h->serial_pipe ? 3 : 1], evq[2]));
     } else {  // pipelined: stage 1 summed over the chunks, stage 2 = the rest of the call's wall time on the stream
         float total = 0.f;
         HIP_TRY(hipEventElapsedTime(&total, evq[0], evq[2]));

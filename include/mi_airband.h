@@ -178,7 +178,8 @@ int mi_demod_kernel_time_prev(mi_demod* h, int age, int index, const char** name
  * mi_demod_process_device() are valid when the call is made (not merely in the order of `hip_stream`), e.g. a capture
  * already resident in HBM or a ring filled by a copy engine the caller has synchronised with.  The library may then read
  * them before the work queued earlier on `hip_stream` has finished, which lets stage 1 and the serial core chain of a call
- * overlap the segment / fix passes of the previous call (time-parallel path).  Outputs still complete in stream order.
+ * overlap the segment / fix passes of the previous call (time-parallel path), or stage 1 overlap the channel loop of the
+ * previous call (serial path; a second set of planes is allocated on first use).  Outputs still complete in stream order.
  * The audio buffer of a call must then also be free when the call is made (no reader of an earlier result still pending on
  * another stream): when it is not the buffer of the previous call, the segment passes may write it early.
  * MI_OPT_STEADY_BLOCKS (default 1, or 0 when MI_AIRBAND_STEADY=0 is in the environment): the serial stage 2 takes runs

@@ -734,3 +734,68 @@ def test_steady_blocks_random_plans(pkg, seed):
         assert_same(a[2], b[2], f"raw I/Q, call {call}")
         assert a[3] == b[3], f"statistics differ after call {call}"
         assert_same(a[4], b[4], f"checkpoint state, call {call}")
+
+
+@pytest.mark.parametrize("nstreams", [1, 3])
+def test_serial_calls_overlap_with_early_input(pkg, nstreams):
+    """MI_OPT_EARLY_INPUT on a plan the time-parallel path cannot take (AM + NFM + low-pass + CTCSS + notch + raw I/Q): stage 1
+    of call k+1 runs under k_demod of call k on two alternating plane sets, the carried head written across.  Calls of
+    different sizes enqueued back to back, a checkpoint taken in the middle and restored into a fresh handle; audio, flags
+    and raw I/Q equal the oracle's, and the kernel timings of the pipelined calls are readable."""
+    import torch
+    centre, chans = _channel_zoo(pkg)
+    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=9)
+    calls = [3, 1, 4, 2, 5, 1]
+    nbat = sum(calls)
+    iqs = [_zoo_capture(pkg, dev, centre, chans, nbat, 31 + 7 * st) for st in range(nstreams)]
+    oracle = [oracle_run(dev, chans, iq, nbat, want_iq=True) for iq in iqs]
+    stride = (max(iq.size for iq in iqs) + 255) // 256 * 256
+    d_iq = torch.zeros((nstreams, stride), dtype=torch.uint8, device="cuda")
+    for st, iq in enumerate(iqs):
+        d_iq[st, :iq.size] = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    s = torch.cuda.current_stream().cuda_stream
+    nch = len(chans)
+
+    def run(d, todo, done, outs):
+        for k in todo:
+            pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+            wo = torch.empty((nstreams, nch, k * WAVE_BATCH), dtype=torch.float32, device="cuda")
+            ax = torch.empty((nstreams, nch, k), dtype=torch.uint8, device="cuda")
+            zo = torch.empty((nstreams, nch, k * WAVE_BATCH, 2), dtype=torch.float32, device="cuda")
+            d.process_device(d_iq.data_ptr() + pos, stride, k, wo.data_ptr(), ax.data_ptr(), d_iq_out_ptr=zo.data_ptr(), hip_stream=s)
+            outs.append((wo, ax, zo))
+            done += k
+        return done
+
+    d = pkg.Demod(dev, chans, nstreams=nstreams, max_batches=max(calls))
+    d.set_option(pkg.OPT_EARLY_INPUT, 1)
+    outs = []
+    done = run(d, calls[:3], 0, outs)
+    times = d.kernel_times()
+    assert [t[0] for t in times] == ["k_channelize", "k_demod"] and all(t[1] > 0 for t in times)
+    blob = d.get_state()  # drains the calls in flight
+    done2 = run(d, calls[3:], done, outs)
+    torch.cuda.synchronize()
+    d.close()
+    e = pkg.Demod(dev, chans, nstreams=nstreams, max_batches=max(calls))
+    e.set_option(pkg.OPT_EARLY_INPUT, 1)
+    e.set_state(blob)
+    outs_e = []
+    run(e, calls[3:], done, outs_e)
+    torch.cuda.synchronize()
+    e.close()
+    assert done2 == nbat
+    wo = torch.cat([o[0] for o in outs], dim=2).cpu().numpy()
+    ax = torch.cat([o[1] for o in outs], dim=2).cpu().numpy()
+    zo = torch.cat([o[2] for o in outs], dim=2).cpu().numpy()
+    for st in range(nstreams):
+        nb, owo, oaxc, oiq = oracle[st]
+        assert_same(ax[st], oaxc, f"flags, stream {st}")
+        assert_same(wo[st], owo, f"audio, stream {st}")
+        for c, ch in enumerate(chans):
+            if ch.has_iq_outputs:
+                assert_same(zo[st, c].reshape(-1), oiq[c], f"raw I/Q, stream {st} channel {c}")
+    for (a, b) in zip(outs[3:], outs_e):
+        assert_same(b[0].cpu().numpy(), a[0].cpu().numpy(), "audio after restoring the checkpoint")
+        assert_same(b[1].cpu().numpy(), a[1].cpu().numpy(), "flags after restoring the checkpoint")
