@@ -161,12 +161,17 @@ constexpr int kTpMinBatches = 8;  // below this the segments are too few to pay 
 
 // The pruned stage-1 graph (PrunePlan, k_channelize9p) is bit-exact and about 10 % faster where it applies (N = 512, no AFC,
 // few residues among the bins): on unless MI_AIRBAND_PRUNE=0.
-bool conv_lut_forced() {  // MI_AIRBAND_CONV_LUT=1: keep the level table for u8 (A/B measurement)
-    static const bool on = [] {
-        const char* e = std::getenv("MI_AIRBAND_CONV_LUT");
-        return e && std::atoi(e) != 0;
+// u8 conversion: the level table in LDS or the arithmetic form the plan has checked against it.  Measured on 64 streams:
+// the table is 3 % faster in the pruned N = 512 kernel, the arithmetic 1.5 % faster in the full-graph kernels: that is the
+// default; MI_AIRBAND_CONV=lut / arith forces one (A/B measurements, tests).
+int conv_choice() {  // -1 auto, 0 table, 1 arithmetic
+    static const int c = [] {
+        const char* e = std::getenv("MI_AIRBAND_CONV");
+        if (!e || !*e)
+            return -1;
+        return (e[0] == 'a' || e[0] == 'A') ? 1 : 0;
     }();
-    return on;
+    return c;
 }
 bool steady_blocks_wanted() {  // MI_AIRBAND_STEADY=0: the serial stage 2 takes every step in the sample loop (A/B, tests)
     static const bool on = [] {
@@ -246,7 +251,11 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     ca.prune_t2 = h->d_prune_t2;
     ca.prune_rank = h->d_prune_rank;
     ca.levels = h->d_levels;
-    ca.conv_arith = (h->plan.conv_arith && !conv_lut_forced()) ? 1 : 0;
+    {
+        const bool pruned = ca.prune.enabled && h->plan.log2n == 9 && !h->plan.any_afc;
+        const int cc = conv_choice();
+        ca.conv_arith = (h->plan.conv_arith && (cc < 0 ? !pruned : cc == 1)) ? 1 : 0;
+    }
     ca.conv_scale = h->plan.conv_scale;
     ca.cp = h->d_cp;
     ca.nch = h->nch;

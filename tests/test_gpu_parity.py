@@ -565,8 +565,9 @@ def test_checkpoint_between_overlapping_calls_and_timing_ages(pkg, monkeypatch):
 
 def test_stage1_alternative_instantiations_keep_every_bit(pkg, tmp_path):
     """By default stage 1 evaluates, at N = 512, only the nodes of the radix-2 graph that feed the picked bins (PrunePlan) and
-    converts u8 samples arithmetically; every other test here runs that way.  MI_AIRBAND_PRUNE=0 / MI_AIRBAND_CONV_LUT=1 select
-    the full graph and the level table: any subset of the graph is computed with the same operations and the conversion is
+    takes u8 samples through the level table there (arithmetically in the full-graph kernels); every other test here runs that
+    way.  MI_AIRBAND_PRUNE=0 with MI_AIRBAND_CONV=lut, and MI_AIRBAND_CONV=arith with the pruned graph, select the other
+    combinations: any subset of the graph is computed with the same operations and the conversion is
     checked against the table value by value, so audio and raw I/Q stay bit-exact.  Fresh process: the switches are read once."""
     import subprocess
     import sys
@@ -594,9 +595,10 @@ def test_stage1_alternative_instantiations_keep_every_bit(pkg, tmp_path):
         "        if ch.has_iq_outputs:\n"
         "            assert np.array_equal(iqo[0, c].reshape(-1), oiq[c]), (name, c)\n"
         "print('stage1 ok')\n")
-    env = dict(os.environ, MI_AIRBAND_PRUNE="0", MI_AIRBAND_CONV_LUT="1")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0 and "stage1 ok" in r.stdout, r.stdout + r.stderr
+    for extra in (dict(MI_AIRBAND_PRUNE="0", MI_AIRBAND_CONV="lut"), dict(MI_AIRBAND_CONV="arith")):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "stage1 ok" in r.stdout, r.stdout + r.stderr
 
 
 def _channel_zoo(pkg):
