@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Determinism stress for the overlapped pipeline: the same sequence of device-resident calls, enqueued back to back with
 MI_OPT_EARLY_INPUT, must give bit-identical audio every time (a race between a call's tail and the next call's early
-stages would show up as a difference).  Compared against a run without the option."""
+stages would show up as a difference).  Compared against a run without the option.
+STRESS_MODE=serial: a mixed 32-channel plan, whose calls take the serial kernel and overlap on two alternating plane sets."""
 import os
 import sys
 
@@ -15,11 +16,12 @@ from bench import load_package  # noqa: E402
 from common import AGC_EXTRA, WAVE_BATCH, gen_iq  # noqa: E402
 
 pkg = load_package()
-centre, chans = pkg.config2_channels()
+serial = os.environ.get("STRESS_MODE") == "serial"
+centre, chans = pkg.config3_channels() if serial else pkg.config2_channels()
 dev = pkg.device_cfg(centerfreq=centre)
-calls = [64, 96, 64, 128, 32, 64]
+calls = [6, 9, 1, 12, 3, 6, 2, 7] if serial else [64, 96, 64, 128, 32, 64]
 nbat = sum(calls)
-iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=3)
+iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=3, **(dict(amp_q8=1024, active=lambda k: k % 4 != 2) if serial else {}))
 pad = (iq.size + 255) // 256 * 256
 d_iq = torch.zeros(pad, dtype=torch.uint8, device="cuda")
 d_iq[:iq.size] = torch.from_numpy(iq).cuda()
