@@ -66,8 +66,8 @@ def cpu_baseline(pkg, dev, centre, chans, seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seconds", type=float, default=64.0, help="capture length per stream per step (HBM-resident)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="length of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--noise-only", action="store_true", help="diagnostic: no carriers in the synthetic capture (squelch never opens)")
