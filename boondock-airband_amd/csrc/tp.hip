@@ -395,32 +395,49 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                         // Stay here for them (noise floor step, cap, trial) instead of going round the hypothesis logic;
                         // a block whose trial fails is left to the general path, which is exact for any block.
                         float fe_k = fe;
+                        // The blocks after it, eight per round, systolic over the lanes at block granularity: lane j steps its
+                        // own block (noise floor, cap, trial) from what lane j-1 left, so lane kk+t is final after t rounds of
+                        // the same straight-line code -- no lane reads, no compare -> branch round trips between the blocks
+                        // (there were five per block).  Lanes up to kk are switched off: lane kk+1 finds no valid shifted
+                        // source and takes the current state instead.  Every lane judges its own block: it exists, its full_
+                        // is valid, the cap does not bind in it (trial maximum below the block's cap), and capped_ has not met
+                        // full_ at its start (the hypothesis path is cheaper from there).  The leading run of acceptable
+                        // blocks is committed; a block that is not is left to the general path, which is exact for any block.
+                        float nfL = nf, capL = cap, cL = c;  // state after the lane's block
                         while (kk + 1 < nb && c != fe_k) {
-                            const int k1 = kk + 1;
-                            const float fm1 = rl(cur.fm, k1);
-                            if (!(fm1 >= 0.0f))
+                            constexpr int kRound = 8;
+                            bool ok = false;
+                            float nf_in = nf, cap_in = cap, c_in = c;
+                            if (lane > kk) {
+#pragma unroll 1
+                                for (int t = 0; t < kRound; ++t) {
+                                    c_in = wave_shr1(cL, c);
+                                    nf_in = wave_shr1(nfL, nf);
+                                    cap_in = wave_shr1(capL, cap);
+                                    const float nf1 = noise_floor_step(nf_in, c_in);
+                                    const float cap1 = cap_of(p, nf1);
+                                    float cs1, em1;
+                                    ema_trial(yv, c_in, cs1, em1);
+                                    ok = cur.fm >= 0.0f && em1 < cap1 && c_in != fe_prev;
+                                    nfL = nf1, capL = cap1, cL = cs1;
+                                }
+                            }
+                            const int nacc = min(min(trailing_ones_from(__ballot(ok), kk + 1), kRound), nb - 1 - kk);
+                            if (nacc == 0)
                                 break;
-                            if ((g0 + k1) % bps == 0 && lane == 0) {
-                                TpCore t;
-                                t.nf = nf, t.cap = cap, t.c = c, t.full = fe_k;
-                                core[(g0 + k1) / bps] = t;
+                            if (boundary && lane > kk && lane <= kk + nacc) {
+                                TpCore t;  // the state at the start of the lane's block
+                                t.nf = nf_in, t.cap = cap_in, t.c = c_in, t.full = fe_prev;
+                                core[(g0 + lane) / bps] = t;
                             }
-                            const float nf1 = noise_floor_step(nf, c);
-                            const float cap1 = cap_of(p, nf1);
-                            if (c <= fe_k && fm1 < cap1) {
-                                // capped_ <= full_ at the block start and both follow the same monotone recurrence while the
-                                // cap does not bind, so capped_ <= full_ <= fm1 < cap throughout: no maximum to track
-                                ema_only(yv, c, cs_l);
-                                cs = rl(cs_l, k1);
-                            } else {
-                                ema_trial(yv, c, cs_l, emax_l);
-                                cs = rl(cs_l, k1), emax = rl(emax_l, k1);
-                                if (!(emax < cap1))
-                                    break;
-                            }
-                            nf = nf1, cap = cap1, c = cs, kk = k1;
-                            fe_k = rl(cur.fe, k1);
-                            ++n_step;
+                            kk += nacc;
+                            nf = rl(nfL, kk);
+                            cap = rl(capL, kk);
+                            c = rl(cL, kk);
+                            fe_k = rl(cur.fe, kk);
+                            n_step += nacc;
+                            if (nacc < kRound)
+                                break;
                         }
                         fe = fe_k;
                     } else {
