@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                         // blocks is committed; a block that is not is left to the general path, which is exact for any block.
                         float nfL = nf, capL = cap, cL = c;  // state after the lane's block
                         while (kk + 1 < nb && c != fe_k) {
-                            constexpr int kRound = 8;
+                            constexpr int kRound = 16;
                             bool ok = false;
                             float nf_in = nf, cap_in = cap, c_in = c;
                             if (lane > kk) {
