@@ -329,8 +329,11 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         // aggregates are all that precedes it), later chunks are long because every wide pass has a fixed latency per
         // launch.  MI_AIRBAND_TP_CHUNKS / MI_AIRBAND_TP_RATIO override the measured defaults.
         // An isolated call: 3 chunks growing by 1.5x.  When calls overlap the chain is already running and stage 1 of this
-        // call hides under the previous call: two equal chunks measured best (2 / 3 / 4 chunks: 2.93 / 3.2 / 3.7 ms per step).
-        int want = overlap ? 2 : 3;
+        // call hides under the previous call: one chunk then -- every chunk boundary costs the chain a launch gap and the
+        // tail passes on the caller's stream (scan / fix / redo / settle / finish) their fixed latencies once more, and with
+        // two chunks those passes took as long per call as the chain itself (1 / 2 / 3 / 4 chunks over 20 steps: 2.21 / 2.40 /
+        // 2.9 / 3.5 ms per step; over 5 steps, where the last call's drain weighs more, 1 and 2 are level).
+        int want = overlap ? 1 : 3;
         double ratio = overlap ? 1.0 : 1.5;
         if (const char* e = std::getenv("MI_AIRBAND_TP_CHUNKS"))
             want = std::max(1, std::atoi(e));
