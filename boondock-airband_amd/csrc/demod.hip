@@ -423,7 +423,7 @@ struct BlockIo {
 #ifdef MI_BLOCK_PROF
     unsigned long long prof[8];
     unsigned long long prof_t;
-    unsigned long long blocks, steps;
+    unsigned long long blocks, steps, after_ret;
 #endif
     float* magrow;
     const float2* zrow;
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
         nz0 = zg[0], nz1 = zg[1];
 
 #ifdef MI_BLOCK_PROF
-    BlockIo bio{{0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, magrow, zrow, wmain, carry, iqo, n, 0.0f, 0xffffffffu};
+    BlockIo bio{{0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0, magrow, zrow, wmain, carry, iqo, n, 0.0f, 0xffffffffu};
     const unsigned long long prof_k0 = __builtin_readcyclecounter();
 #else
     BlockIo bio{magrow, zrow, wmain, carry, iqo, n, 0.0f, 0xffffffffu};
@@ -927,6 +927,13 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
                           stale = true;  // the group fetched ahead is behind us now
                           if (kc < 8)
                               skip = 8;
+#ifdef MI_BLOCK_PROF
+                          {   // (experiment) split "between blocks": bookkeeping after the return vs loop head + eligibility
+                              const unsigned long long t_ = __builtin_readcyclecounter();
+                              bio.after_ret += t_ - bio.prof_t;
+                              bio.prof_t = t_;
+                          }
+#endif
                           --gi;  // the loop increment
                           continue;
                       }
@@ -1171,8 +1178,8 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
 
 #ifdef MI_BLOCK_PROF
     if (kUni && row == 0 && threadIdx.x == 0)
-        printf("blockprof row0: total %llu cyc, %llu blocks, %llu of %u steps in blocks; loads %llu between blocks %llu pre %llu level+lsc %llu filter %llu post %llu audio %llu commit %llu\n",
-               __builtin_readcyclecounter() - prof_k0, bio.blocks, bio.steps, n, bio.prof[6], bio.prof[7], bio.prof[0], bio.prof[1], bio.prof[2], bio.prof[3], bio.prof[4], bio.prof[5]);
+        printf("blockprof row0: total %llu cyc, %llu blocks, %llu of %u steps in blocks; after-return %llu loads %llu between blocks %llu pre %llu level+lsc %llu filter %llu post %llu audio %llu commit %llu\n",
+               __builtin_readcyclecounter() - prof_k0, bio.blocks, bio.steps, n, bio.after_ret, bio.prof[6], bio.prof[7], bio.prof[0], bio.prof[1], bio.prof[2], bio.prof[3], bio.prof[4], bio.prof[5]);
 #endif
     // plane carry: the last AGC_EXTRA (possibly low-pass-rewritten) magnitudes and raw bins move to the front,
     // the reference's memmove (rtl_airband.cpp:643-646)
