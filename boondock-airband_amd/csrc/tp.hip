@@ -228,18 +228,19 @@ struct CoreGroup {  // what lane l holds for block g0 + l
 };
 
 __device__ __forceinline__ CoreGroup core_load(const TpArgs& a, const float* __restrict__ x, const size_t bbase, const uint32_t g0, const int lane) {
+    // Unconditional loads from a clamped block index: a value that is merged with a default at a join costs a register copy
+    // per group and a wait at the join.  Lanes past the chunk read its last block; nobody looks at them (nb bounds every
+    // use), fm = -1 only marks them for good measure.
     CoreGroup g;
-    g.fe = 0.f, g.fm = -1.f, g.x0 = 0.f, g.xm = 0.f;
-    g.s0 = g.s1 = g.s2 = g.s3 = make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t mine = g0 + lane;
-    if (mine < a.blk1) {
-        g.fe = a.blk_fe[bbase + mine];
-        g.fm = a.blk_fm[bbase + mine];
-        g.x0 = a.blk_x0[bbase + mine];
-        g.xm = a.blk_xm[bbase + mine];
-        const float4* __restrict__ sp = reinterpret_cast<const float4*>(x + static_cast<size_t>(mine) * 16);
-        g.s0 = sp[0], g.s1 = sp[1], g.s2 = sp[2], g.s3 = sp[3];
-    }
+    const uint32_t at = min(mine, a.blk1 - 1u);
+    g.fe = a.blk_fe[bbase + at];
+    const float fm = a.blk_fm[bbase + at];
+    g.x0 = a.blk_x0[bbase + at];
+    g.xm = a.blk_xm[bbase + at];
+    const float4* __restrict__ sp = reinterpret_cast<const float4*>(x + static_cast<size_t>(at) * 16);
+    g.s0 = sp[0], g.s1 = sp[1], g.s2 = sp[2], g.s3 = sp[3];
+    g.fm = mine < a.blk1 ? fm : -1.0f;
     return g;
 }
 
@@ -290,8 +291,7 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
     for (uint32_t g0 = a.blk0; g0 < nblk; g0 += 64) {
         const CoreGroup cur = nxt;
         nxt = nxt2;
-        if (g0 + 128 < nblk)
-            nxt2 = core_load(a, x, bbase, g0 + 128, lane);  // two groups in flight while this one is walked
+        nxt2 = core_load(a, x, bbase, g0 + 128, lane);  // two groups in flight while this one is walked (past the end: the last block again)
         const int nb = static_cast<int>(min(64u, nblk - g0));
         const float fe_prev = wave_shr1(cur.fe, 0.0f);  // full_ at the start of lane's block, valid for lane > kk
         const bool boundary = ((g0 + lane) % bps) == 0;
