@@ -66,7 +66,7 @@ def cpu_baseline(pkg, dev, centre, chans, seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seconds", type=float, default=64.0, help="capture length per stream per step (HBM-resident)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="length of the CPU-baseline sample (0 = skip)")
@@ -129,7 +129,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-    nbuf = 2  # consecutive steps write alternate audio buffers: the segment passes of step k+1 may run under the tail of step k
+    nbuf = 3  # consecutive steps write different audio buffers (the segment passes of step k+1 may run under the tail of step k), three deep like the timing reads
     d_wos = [torch.empty((nstreams, nch, nsteps), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
     d_wo = d_wos[0]
     d_axc = torch.empty((nstreams, nch, nbat), dtype=torch.uint8, device="cuda")
@@ -148,7 +148,8 @@ def main():
     kms = {}  # kernel name -> [total ms over the timed steps, launches]
 
     nstep = [0]
-    timed_hist = [False, False]  # was the step one / two steps ago a timed one
+    TIMING_AGE = 3
+    timed_hist = [False] * TIMING_AGE  # was the step one / two / three steps ago a timed one
 
     def add_times(times):
         for name, ms, launches in times:  # HIP events around the launches, on the launch streams
@@ -170,10 +171,12 @@ def main():
         h.process_device(base, nbytes - AGC_EXTRA * hop, nbat, d_wos[b].data_ptr(), d_axc.data_ptr(), hip_stream=stream.cuda_stream)
         if gathering:
             pending[b] = dist.gather(d_wos[b], gather_lists[b], dst=0, async_op=True)
-        # the timings of a step are read two steps later, so that reading them does not drain the pipeline
-        if timed_hist[1]:
-            add_times(h.kernel_times(age=2))
-        timed_hist[1], timed_hist[0] = timed_hist[0], timed
+        # the timings of a step are read three steps later, so that reading them does not drain the pipeline (the tail of a
+        # call ends about one call after its core chain: with a depth of two the next call's front started late now and then)
+        if timed_hist[-1]:
+            add_times(h.kernel_times(age=TIMING_AGE))
+        timed_hist.pop()
+        timed_hist.insert(0, timed)
 
     for _ in range(args.warmup):
         step(False)
@@ -188,11 +191,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
-    if timed_hist[1]:
-        add_times(h.kernel_times(age=1))
-    if timed_hist[0]:
-        add_times(h.kernel_times())  # (synchronises with the end of the last step)
-    timed_hist[0] = timed_hist[1] = False
+    for age in range(TIMING_AGE - 1, -1, -1):  # the steps whose timings have not been read yet, oldest first
+        if timed_hist[age]:
+            add_times(h.kernel_times(age=age))  # (age 0 synchronises with the end of the last step)
+        timed_hist[age] = False
     for b in range(nbuf):  # every gather of the timed steps completes inside the timed region
         if pending[b] is not None:
             pending[b].wait()

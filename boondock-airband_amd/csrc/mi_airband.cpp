@@ -73,7 +73,10 @@ struct mi_demod {
     // passes of a call never touch what the tails of the two calls before it still read, so calls overlap (see enqueue()).
     // `cur` is the set of the last call; the serial path stays on it.
     int cur = 0;
-    static constexpr int kSets = 3;  // a call writes the set of the call three back: by then that call has long finished
+    // a call writes the set of the call four back: the host may then keep three calls queued behind the one whose timings it
+    // reads (mi_demod_kernel_time_prev, age 3) -- the tail of a call ends about one call after its core chain, and with only two
+    // queued the front of the next call started late every few calls
+    static constexpr int kSets = 4;
     hipEvent_t ev[kSets][4] = {};  // per call: 0 begin, 1 stage 1 done, 2 call done, 3 serial k_demod begins (pipelined serial calls)
     static constexpr int kMaxChunks = 64, kEvPerChunk = 13, kSegStreams = 1;
     std::vector<hipEvent_t> chunk_ev[kSets];  // per chunk: stage1 begin/end, full end, core begin/end, seg begin/end, scan0/fix0/finish ends, rest begin
