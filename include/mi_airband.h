@@ -169,7 +169,7 @@ int mi_demod_last_kernel_ms(mi_demod* h, float* channelize_ms, float* demod_ms);
  * sum over those launches (kernels of different chunks and calls overlap on several streams, so the sums exceed the wall time).
  * Returns MI_ERR_INVALID past the last index: iterate from 0 until it fails.  *name is a static string. */
 int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms_total, int* launches);
-/* The same for an earlier call: age 1 = the call before the last one, age 2 = the one before that (while the event set has
+/* The same for an earlier call: age 1 = the call before the last one, age 2, 3 = the ones before that (while the event set has
  * not been reused; serial calls reuse the set of the call before them).  Lets a caller that keeps calls in flight read the
  * timings of call k after it has enqueued calls k+1, k+2, without draining the pipeline. */
 int mi_demod_kernel_time_prev(mi_demod* h, int age, int index, const char** name, float* ms_total, int* launches);
