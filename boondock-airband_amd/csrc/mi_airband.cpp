@@ -336,7 +336,10 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         // tail passes on the caller's stream (scan / fix / redo / settle / finish) their fixed latencies once more, and with
         // two chunks those passes took as long per call as the chain itself (1 / 2 / 3 / 4 chunks over 20 steps: 2.21 / 2.40 /
         // 2.9 / 3.5 ms per step; over 5 steps, where the last call's drain weighs more, 1 and 2 are level).
-        int want = overlap ? 1 : 3;
+        // (that is the few-rows case, where the per-channel chain is the critical path; with hundreds of rows the wide passes
+        // are, and two chunks let stage 1 of the second run under the segment / fix passes of the first: 64 streams x 8
+        // channels 168 vs 147 GS/s)
+        int want = overlap ? (h->rows <= 64 ? 1 : 2) : 3;
         double ratio = overlap ? 1.0 : 1.5;
         if (const char* e = std::getenv("MI_AIRBAND_TP_CHUNKS"))
             want = std::max(1, std::atoi(e));
