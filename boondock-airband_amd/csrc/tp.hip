@@ -260,13 +260,6 @@ __device__ __forceinline__ void ema_trial(const float (&ys)[16], const float c, 
     }
 }
 
-__device__ __forceinline__ void ema_only(const float (&ys)[16], const float c, float& cs) {
-    cs = c;
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-        cs = cs * 0.99f + ys[j];
-}
-
 __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
     // The chain is the critical path of a call and shares its SIMD with waves of the wide passes of other chunks: ask the
     // issue arbiter to favour it.
