@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import conftest, test_gpu_parity as T
 pkg = conftest.load_package()
 bad = 0
-for seed in range(5, 65):
+first, last = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (5, 65)
+for seed in range(first, last):
     try:
         T.test_steady_blocks_random_plans(pkg, seed)
     except AssertionError as e:
