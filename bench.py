@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--workload", choices=["config2", "config3", "config4", "am64"], default="config2",
                     help="config2 = BASELINE configs[1], the bench line (default); config3 = 1 stream x 32 mixed AM/NFM/CTCSS channels at fft 2048; "
                          "config4 = 64 streams x the config-3 plan at fft 512; am64 = 64 streams x the config-2 plan (extra measurements, not the driver's line)")
+    ap.add_argument("--streams", type=int, default=0, help="with --workload am64: this many streams instead of 64")
     args = ap.parse_args()
 
     import torch
@@ -99,7 +100,7 @@ def main():
         centre, chans = pkg.config2_channels()
     elif args.workload == "am64":
         centre, chans = pkg.config2_channels()
-        nstreams = 64
+        nstreams = args.streams or 64  # (--streams: the stream-count sweep of DESIGN.md section 6)
         if args.seconds == 64.0:
             args.seconds = 8.0
         args.cpu_seconds = 0.0
