@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the demodulate() hot path on MI355X (BASELINE.json metric).
 
-Workload (config.workload): BASELINE configs[1] -- per GPU ONE device stream of synthetic 2.56 MS/s u8 IQ,
-8 AM channels, fft_size 512 (SURVEY 8d channel plan and signal recipe).  A "step" is one pass of the whole
-path (channelize kernel + demod kernel, through the C ABI's device-resident entry) over `--seconds` of
-capture already resident in HBM.  With N GPUs each rank owns its own stream (independent dongles, weak
-scaling) and the decimated audio of every rank is gathered to rank 0 over RCCL inside the timed region.
+Workload of the JSON line (config.workload): BASELINE configs[1] -- per GPU ONE device stream of synthetic 2.56 MS/s u8 IQ,
+8 AM channels, fft_size 512 (SURVEY 8d channel plan and signal recipe).  A "step" is one pass of the whole path (stage 1
++ stage 2, through the C ABI's device-resident entry) over `--seconds` of capture already resident in HBM.  With N GPUs the
+streams shard stream-major over the ranks (boondock-airband_amd/shard.py: independent dongles, weak scaling, no data-path
+collective) and the decimated audio + batch flags of every rank are gathered to rank 0 over RCCL inside the timed region.
+With N > 1 the same line also carries `config5`: BASELINE configs[4] (64 streams x 32 mixed channels per GPU, fft 512)
+measured with the full gather, with the open-batches-only gather and without the gather.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  `roofline` is for the kernel that dominates the step, from HIP events the
-library records on its launch stream around each kernel; `cpu_baseline` is the CPU oracle (a port of the
-reference path, oracle/airband_oracle.c) timed on one host core over a bounded sample of the same workload.
+Prints ONE JSON line on rank 0.  `roofline`: the kernel with the largest time per step, from HIP events the library records
+on its launch streams around each kernel; `achieved` = SURVEY 8(d) algorithmic bytes per sample x the samples one launch
+covers / that kernel's mean launch duration (`frac_path`: the same bytes / the step's wall time; `alu_frac`: algorithmic
+flops / step time / 157.3 TFLOP/s fp32 vector).  `cpu_baseline` is the CPU oracle (a port of the reference path,
+oracle/airband_oracle.c) timed on one host core over a bounded sample of the same workload.
 """
 import argparse
+import hashlib
 import importlib.util
 import json
 import os
@@ -25,11 +30,21 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_PROFILE = "r01_final_pmc.csv"
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_PEAK_TFLOPS = 157.3  # same guide: peak fp32 vector
+PMC_PROFILE = "r02_pmc.csv"
 SAMPLE_RATE = 2560000
 WAVE_BATCH = 2000
 AGC_EXTRA = 100
+HOP = SAMPLE_RATE // 16000  # complex samples per output sample
+
+WORKLOADS = {
+    "config2": "BASELINE configs[1]: 1 device stream per GPU @ 2.56 MS/s u8 IQ, 8 AM channels, fft_size=512",
+    "config3": "BASELINE configs[2]: 1 device stream, 32 channels mixed AM+NFM + CTCSS, fft_size=2048",
+    "config4": "BASELINE configs[3]: 64 device streams x 32 mixed channels per GPU, fft_size=512",
+    "config5": "BASELINE configs[4]: 64 device streams x 32 mixed channels per GPU (512 streams on 8 GPUs), fft_size=512, gather to rank 0",
+    "am64": "64 device streams x 8 AM channels per GPU, fft_size=512",
+}
 
 
 def load_package():
@@ -52,7 +67,7 @@ def cpu_baseline(pkg, dev, centre, chans, seconds):
     t0 = time.perf_counter()
     nb, _, _, _ = oracle_run(dev, chans, iq, nbat)
     dt = time.perf_counter() - t0
-    samples = nb * WAVE_BATCH * (SAMPLE_RATE // 16000)
+    samples = nb * WAVE_BATCH * HOP
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
@@ -63,90 +78,67 @@ def cpu_baseline(pkg, dev, centre, chans, seconds):
             "x_realtime": samples / dt / SAMPLE_RATE}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--seconds", type=float, default=64.0, help="capture length per stream per step (HBM-resident)")
-    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="length of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--noise-only", action="store_true", help="diagnostic: no carriers in the synthetic capture (squelch never opens)")
-    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of audio to rank 0 (N>1)")
-    ap.add_argument("--diag", action="store_true", help="print the time-parallel path's per-channel counters to stderr")
-    ap.add_argument("--no-overlap", action="store_true", help="do not let consecutive steps overlap (MI_OPT_EARLY_INPUT off)")
-    ap.add_argument("--workload", choices=["config2", "config3", "config4", "am64"], default="config2",
-                    help="config2 = BASELINE configs[1], the bench line (default); config3 = 1 stream x 32 mixed AM/NFM/CTCSS channels at fft 2048; "
-                         "config4 = 64 streams x the config-3 plan at fft 512; am64 = 64 streams x the config-2 plan (extra measurements, not the driver's line)")
-    ap.add_argument("--streams", type=int, default=0, help="with --workload am64: this many streams instead of 64")
-    args = ap.parse_args()
+def workload_shape(pkg, workload, streams, seconds):
+    """(centre, channels, streams per GPU, fft_size_log, capture seconds per step)"""
+    if workload == "config2":
+        centre, chans = pkg.config2_channels()
+        return centre, chans, 1, 9, seconds or 64.0
+    if workload == "am64":
+        centre, chans = pkg.config2_channels()
+        return centre, chans, streams or 64, 9, seconds or 8.0
+    centre, chans = pkg.config3_channels()
+    if workload == "config3":
+        return centre, chans, 1, 11, seconds or 8.0
+    return centre, chans, streams or 64, 9, seconds or 2.0  # config4 / config5
 
+
+def run_workload(pkg, args, workload, steps, warmup, gather_mode, rank, world, local_rank):
+    """Times `steps` steps of one workload.  gather_mode: None | "full" | "open" (open batches only)."""
     import torch
     import torch.distributed as dist
+    from boondock_airband_amd import shard
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    pkg = load_package()
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    nstreams, fft_log = 1, 9
-    if args.workload == "config2":
-        centre, chans = pkg.config2_channels()
-    elif args.workload == "am64":
-        centre, chans = pkg.config2_channels()
-        nstreams = args.streams or 64  # (--streams: the stream-count sweep of DESIGN.md section 6)
-        if args.seconds == 64.0:
-            args.seconds = 8.0
-        args.cpu_seconds = 0.0
-    else:
-        centre, chans = pkg.config3_channels()
-        nstreams, fft_log = (1, 11) if args.workload == "config3" else (64, 9)
-        if args.seconds == 64.0:
-            args.seconds = 8.0 if args.workload == "config3" else 2.0
-        args.cpu_seconds = 0.0
+    centre, chans, nstreams, fft_log, seconds = workload_shape(pkg, workload, args.streams, args.seconds)
     dev = pkg.device_cfg(centerfreq=centre, fft_size_log=fft_log)
     nch = len(chans)
-    nbat = max(1, int(round(args.seconds * 8)))
+    n_iq = sum(1 for c in chans if c.has_iq_outputs)
+    nbat = max(1, int(round(seconds * 8)))
     nsteps = nbat * WAVE_BATCH
-    hop = 2 * (SAMPLE_RATE // 16000)
+    hop = 2 * HOP
     nbytes = ((nsteps + AGC_EXTRA) * hop + 2 * (1 << fft_log) + 255) // 256 * 256
     stream = torch.cuda.current_stream()
 
-    # synthetic capture of this rank's stream, generated on the device (same integer recipe as the host generator)
-    amp = {} if args.workload == "config2" else {"amp_q8": 1024}  # 16 carriers: keep the sum inside the u8 range
-    gcfg = pkg.iqgen_cfg(sample_rate=SAMPLE_RATE, gate_samples=SAMPLE_RATE, carriers=() if args.noise_only else pkg.carriers_for(centre, chans, **amp))
+    # this rank's streams of the job (stream-major partition, the one the gloo test covers); their ids seed the generator
+    lo, hi = shard.stream_range(rank, world, nstreams * world)
+    assert hi - lo == nstreams
+    amp = {} if workload in ("config2", "am64") else {"amp_q8": 1024}  # many carriers: keep the sum inside the u8 range
+    gcfg = pkg.iqgen_cfg(sample_rate=SAMPLE_RATE, gate_samples=SAMPLE_RATE,
+                         carriers=() if args.noise_only else pkg.carriers_for(centre, chans, **amp))
     d_iq = torch.empty((nstreams, nbytes), dtype=torch.uint8, device="cuda")
-    pkg.iqgen_device(gcfg, rank * nstreams, nstreams, nbytes, 0, nbytes // 2, d_iq.data_ptr(), stream.cuda_stream)
-    # The audio of a step is gathered to rank 0 while the next step computes: two output buffers, the gather of buffer b
-    # (RCCL, asynchronous on its own stream) is waited for by the stream only when buffer b is written again.
-    gathering = (world > 1 or os.environ.get("BENCH_FORCE_GATHER") == "1") and not args.no_gather
-    if gathering and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-    nbuf = 3  # consecutive steps write different audio buffers (the segment passes of step k+1 may run under the tail of step k), three deep like the timing reads
+    pkg.iqgen_device(gcfg, lo, nstreams, nbytes, 0, nbytes // 2, d_iq.data_ptr(), stream.cuda_stream)
+
+    # The audio of a step is gathered to rank 0 while the next steps compute: three output buffers, and the host waits for
+    # the gather of buffer b only when buffer b is about to be written again.
+    gathering = gather_mode is not None and dist.is_initialized()
+    nbuf = 3  # consecutive steps write different audio buffers (the segment passes of step k+1 may run under the tail of step k)
     d_wos = [torch.empty((nstreams, nch, nsteps), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
-    d_wo = d_wos[0]
-    d_axc = torch.empty((nstreams, nch, nbat), dtype=torch.uint8, device="cuda")
-    gather_lists = [[torch.empty_like(d_wo) for _ in range(world)] if (gathering and rank == 0) else None for _ in range(nbuf)]
+    d_axcs = [torch.empty((nstreams, nch, nbat), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+    gath = shard.AudioGather((nstreams, nch, nsteps), nbat, torch.device("cuda", local_rank), dst=0) if gathering else None
+    outs = [None] * nbuf
+    if gathering and rank == 0:
+        outs = [([torch.empty(sh, dtype=torch.float32, device="cuda") for sh in gath.shapes],
+                 [torch.empty((sh[0], sh[1], nbat), dtype=torch.uint8, device="cuda") for sh in gath.shapes]) for _ in range(nbuf)]
     pending = [None] * nbuf
 
     h = pkg.Demod(dev, chans, nstreams=nstreams, max_batches=nbat, gpu=local_rank)
     # The capture is resident before the timed region starts: let the library read it without waiting for the previous
-    # step's tail on the stream, so consecutive steps overlap (stage 1 + core chain of step k+1 under the segment / fix
-    # passes of step k).  --no-overlap times every step in isolation.
+    # step's tail on the stream, so consecutive steps overlap.  --no-overlap times every step in isolation.
     if not args.no_overlap:
         h.set_option(pkg.OPT_EARLY_INPUT, 1)
     # prime: the handle's first call consumes AGC_EXTRA extra windows (waveend starts at 0 in the reference)
-    h.process_device(d_iq.data_ptr(), nbytes, nbat, d_wo.data_ptr(), d_axc.data_ptr(), hip_stream=stream.cuda_stream)
+    h.process_device(d_iq.data_ptr(), nbytes, nbat, d_wos[0].data_ptr(), d_axcs[0].data_ptr(), hip_stream=stream.cuda_stream)
     base = d_iq.data_ptr() + AGC_EXTRA * hop
-    kms = {}  # kernel name -> [total ms over the timed steps, launches]
+    kms = {}  # kernel name -> [total ms, launches, steps whose timings were read]
 
     nstep = [0]
     TIMING_AGE = 3
@@ -154,52 +146,51 @@ def main():
 
     def add_times(times):
         for name, ms, launches in times:  # HIP events around the launches, on the launch streams
-            acc = kms.setdefault(name, [0.0, 0])
+            acc = kms.setdefault(name, [0.0, 0, 0])
             acc[0] += ms
             acc[1] += launches
+            acc[2] += 1
 
     def step(timed):
         b = nstep[0] % nbuf
         nstep[0] += 1
         if pending[b] is not None:
-            # The gather of two steps ago still reads this buffer.  With MI_OPT_EARLY_INPUT the library may write a call's
-            # audio before the stream reaches the call, so a stream-side wait is not enough: the host waits (the gather
-            # started when that step finished, a whole step ago, so this normally returns at once).
-            while not pending[b].is_completed():
-                time.sleep(0)
+            # The gather of three steps ago still reads this buffer.  With MI_OPT_EARLY_INPUT the library may write a call's
+            # audio before the stream reaches the call, so a stream-side wait is not enough: the host waits.
             pending[b].wait()
             pending[b] = None
-        h.process_device(base, nbytes - AGC_EXTRA * hop, nbat, d_wos[b].data_ptr(), d_axc.data_ptr(), hip_stream=stream.cuda_stream)
+        # every stream sits `nbytes` after the previous one (the priming call used the same stride)
+        h.process_device(base, nbytes, nbat, d_wos[b].data_ptr(), d_axcs[b].data_ptr(), hip_stream=stream.cuda_stream)
         if gathering:
-            pending[b] = dist.gather(d_wos[b], gather_lists[b], dst=0, async_op=True)
-        # the timings of a step are read three steps later, so that reading them does not drain the pipeline (the tail of a
-        # call ends about one call after its core chain: with a depth of two the next call's front started late now and then)
+            pending[b] = gath.start(d_wos[b], d_axcs[b], open_only=(gather_mode == "open"), out=outs[b])
+        # the timings of a step are read three steps later, so that reading them does not drain the pipeline; calls that
+        # reuse an event set (plain serial calls) have none by then and are skipped -- every read counts one step
         if timed_hist[-1]:
             add_times(h.kernel_times(age=TIMING_AGE))
         timed_hist.pop()
         timed_hist.insert(0, timed)
 
-    for _ in range(args.warmup):
+    def drain():
+        for b in range(nbuf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
+    for _ in range(warmup):
         step(False)
-    for b in range(nbuf):
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(True)
     for age in range(TIMING_AGE - 1, -1, -1):  # the steps whose timings have not been read yet, oldest first
         if timed_hist[age]:
             add_times(h.kernel_times(age=age))  # (age 0 synchronises with the end of the last step)
         timed_hist[age] = False
-    for b in range(nbuf):  # every gather of the timed steps completes inside the timed region
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
+    drain()  # every gather of the timed steps completes inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -210,79 +201,167 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    samples_per_step_per_gpu = nsteps * (SAMPLE_RATE // 16000) * nstreams
-    total_samples = samples_per_step_per_gpu * args.steps * world
-    value = total_samples / dt / 1e6  # MS/s, whole job
-
-    if args.diag and rank == 0 and h.last_path()[0] == 1:
+    samples_per_step_per_gpu = nsteps * HOP * nstreams
+    value = samples_per_step_per_gpu * steps * world / dt / 1e6  # MS/s, whole job
+    path = h.last_path()[0]
+    if args.diag and rank == 0 and path == 1:
         for c in range(nch):
             print(f"diag ch{c}: {h.tp_debug(c)[1].tolist()}", file=sys.stderr)
+    h.close()
+    res = {"value": value, "ms_per_step": dt / steps * 1e3, "nch": nch, "n_iq": n_iq, "nstreams": nstreams, "fft_log": fft_log, "nbat": nbat,
+           "samples_per_step_per_gpu": samples_per_step_per_gpu, "kms": kms, "path": path, "gathering": gathering, "dev": dev,
+           "centre": centre, "chans": chans}
+    return res
+
+
+def kernel_table(res):
+    """Per-kernel lines from the HIP-event sums.  ms / bytes are PER LAUNCH (what rocprofv3's average shows); a long call is
+    processed in chunks, so a kernel runs launches_per_step times per step, each launch over 1/launches_per_step of the step."""
+    nch, n_iq = res["nch"], res["n_iq"]
+    per_sample = {  # algorithmic HBM bytes per complex input sample, per kernel (DESIGN.md "Kernels")
+        "k_channelize": 2.0 + (4.0 * nch + 8.0 * n_iq) / HOP,  # u8 I+Q read once + |bin| (+ raw I/Q) written   (SURVEY 8d)
+        "k_demod": (8.0 * nch + 16.0 * n_iq) / HOP,             # |bin| (+ raw I/Q) read + audio (+ raw I/Q) written
+        "k_tp_full": 5.0 * nch / HOP,                           # |bin| read + 16 B of block aggregates per 16 steps
+        "k_tp_core": 5.0 * nch / HOP,                           # aggregates + raw samples read
+        "k_tp_seg": 8.0 * nch / HOP,                            # |bin| read + audio written
+    }
+    kernels = {}
+    for name, (tot, launches, reads) in res["kms"].items():
+        per_step = launches / reads
+        ms = tot / launches
+        nbytes = res["samples_per_step_per_gpu"] * per_sample.get(name.split("#")[0], 0.0) / per_step
+        kernels[name] = {"ms": ms, "launches_per_step": per_step, "ms_per_step": tot / reads, "steps_timed": reads,
+                         "algorithmic_bytes": nbytes, "GBps": (nbytes / (ms * 1e-3) / 1e9) if ms > 0 and nbytes > 0 else None}
+    return kernels
+
+
+def roofline_block(res, kernels, traffic, traffic_src):
+    nch, n_iq, n = res["nch"], res["n_iq"], 1 << res["fft_log"]
+    path_bytes_per_sample = 2.0 + (4.0 * nch + 8.0 * n_iq) / HOP  # SURVEY 8(d): 2.2 B/sample @ 8 ch, 2.8 @ 32 ch
+    # algorithmic flops per sample (SURVEY 8d): a full N-point FFT per output + the per-channel loop (40-150 flop per
+    # channel and output sample by channel type; 60 for plain AM, 110 as the mixed-plan mean)
+    stage2 = 60.0 if all(c.modulation == 0 and c.bandwidth == 0 for c in res["chans"]) else 110.0
+    flop_per_sample = 5.0 * n * res["fft_log"] / HOP + stage2 * nch / HOP
+    step_s = res["ms_per_step"] * 1e-3
+    sps = res["samples_per_step_per_gpu"]
+    if not kernels:
+        return {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    k = kernels[dom]
+    launch_samples = sps / k["launches_per_step"]
+    achieved = launch_samples * path_bytes_per_sample / (k["ms"] * 1e-3) / 1e9
+    path_gbs = sps * path_bytes_per_sample / step_s / 1e9
+    tflops = sps * flop_per_sample / step_s / 1e12
+    return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic.get(dom.split("#")[0], traffic.get(dom.split("#")[0] + "9p")), "traffic_source": traffic_src,
+            "definition": "achieved = SURVEY 8(d) algorithmic bytes per sample (path_bytes_per_sample) x samples per launch / the dominant "
+                          "kernel's mean launch duration (HIP events on its launch stream)",
+            "path_bytes_per_sample": path_bytes_per_sample,
+            "achieved_path": path_gbs, "frac_path": path_gbs / HBM_PEAK_GBS,  # the same bytes over the step's wall time
+            "kernel_own_GBps": k["GBps"], "frac_kernel_own": (k["GBps"] / HBM_PEAK_GBS) if k["GBps"] else None,
+            "alu": {"flop_per_sample": flop_per_sample, "achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tflops / FP32_PEAK_TFLOPS,
+                    "definition": "5 N log2 N / hop + stage-2 flops per sample, over the step's wall time, against the fp32 vector peak"},
+            "note": "the path is not HBM-bound at fft 512 (65 flop/B): stage 1 is fp32-VALU / LDS bound, stage 2 is a per-channel "
+                    "recurrence; both fractions are reported as SURVEY 8(d) asks"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--seconds", type=float, default=0.0, help="capture length per stream per step (HBM-resident); 0 = the workload's default")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="length of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--noise-only", action="store_true", help="diagnostic: no carriers in the synthetic capture (squelch never opens)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of audio to rank 0 (N>1)")
+    ap.add_argument("--open-only", action="store_true", help="gather only the batches whose squelch flag is not NO_SIGNAL")
+    ap.add_argument("--no-config5", action="store_true", help="N>1: do not add the config5 measurements to the line")
+    ap.add_argument("--diag", action="store_true", help="print the time-parallel path's per-channel counters to stderr")
+    ap.add_argument("--no-overlap", action="store_true", help="do not let consecutive steps overlap (MI_OPT_EARLY_INPUT off)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config2",
+                    help="config2 = BASELINE configs[1], the bench line (default); the others are extra measurements, not the driver's line")
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU for the many-stream workloads (default 64)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    pkg = load_package()
+    torch.cuda.set_device(local_rank)
+    force_gather = os.environ.get("BENCH_FORCE_GATHER") == "1"
+    if world > 1 or force_gather:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    gather_mode = None if (args.no_gather or not dist.is_initialized()) else ("open" if args.open_only else "full")
+    res = run_workload(pkg, args, args.workload, args.steps, args.warmup, gather_mode, rank, world, local_rank)
+
+    extra = {}
+    if world > 1 and not args.no_config5 and args.workload == "config2":
+        # BASELINE configs[4] on the same ranks: short runs, outside the timed region of the line's own metric
+        saved = (args.streams, args.seconds)
+        args.streams, args.seconds = 0, 0.0
+        k5, w5 = max(3, min(args.steps, 10)), 2
+        for label, mode in (("gather_full", "full"), ("gather_open_batches_only", "open"), ("no_gather", None)):
+            r5 = run_workload(pkg, args, "config5", k5, w5, mode, rank, world, local_rank)
+            extra[label] = {"value": r5["value"], "unit": "MS/s", "ms_per_step": r5["ms_per_step"], "steps": k5, "warmup": w5,
+                            "x_realtime_per_stream": r5["value"] / world / r5["nstreams"] / (SAMPLE_RATE / 1e6),
+                            "audio_bytes_to_rank0_per_step": (world - 1) * r5["nstreams"] * r5["nch"] * r5["nbat"] * WAVE_BATCH * 4 if mode == "full" else None}
+        extra["workload"] = WORKLOADS["config5"]
+        extra["streams_total"] = world * 64
+        args.streams, args.seconds = saved
+
     if rank == 0:
-        # algorithmic HBM bytes per complex input sample, per kernel (DESIGN.md "Kernels"); hop = 160 samples
-        hopn = SAMPLE_RATE // 16000
-        per_sample = {
-            "k_channelize": 2.0 + 4.0 * nch / hopn,    # u8 I+Q read once + |bin| written        (2.2 B/sample @ 8 ch)
-            "k_demod": 8.0 * nch / hopn,               # |bin| read + audio written
-            "k_tp_full": 5.0 * nch / hopn,             # |bin| read + 16 B of block aggregates per 16 steps
-            "k_tp_core": 5.0 * nch / hopn,             # aggregates + raw samples read
-            "k_tp_seg": 8.0 * nch / hopn,              # |bin| read + audio written
-        }
-        # A long call is processed in chunks: a kernel runs `launches_per_step` times per step, each launch over
-        # 1/launches_per_step of the samples.  ms / bytes below are PER LAUNCH (what rocprofv3's average shows);
-        # ms_per_step is their sum over the step (kernels of different chunks and steps overlap on several streams).
-        kernels = {}
-        for name, (tot, launches) in kms.items():
-            per_step = launches / args.steps
-            ms = tot / launches
-            nbytes = samples_per_step_per_gpu * per_sample.get(name.split("#")[0], 0.0) / per_step
-            kernels[name] = {"ms": ms, "launches_per_step": per_step, "ms_per_step": tot / args.steps, "algorithmic_bytes": nbytes,
-                             "GBps": (nbytes / (ms * 1e-3) / 1e9) if ms > 0 and nbytes > 0 else None}
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        achieved = kernels[dom]["GBps"]
+        kernels = kernel_table(res)
         # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the bench):
         # only quoted when the launch geometry is the one that was profiled (default --seconds, default chunking).
         traffic, traffic_src = {}, None
         pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
-        if os.path.exists(pmc) and nbat == 512 and args.workload == "config2" and not args.noise_only and "MI_AIRBAND_TP_CHUNKS" not in os.environ:
+        if os.path.exists(pmc) and res["nbat"] == 512 and args.workload == "config2" and not args.noise_only and "MI_AIRBAND_TP_CHUNKS" not in os.environ:
             import csv
             for row in csv.DictReader(open(pmc)):
                 traffic[row["kernel"]] = int(row["hbm_bytes_per_launch"])
-            traffic_src = f"profiles/{PMC_PROFILE}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command, FETCH_SIZE x2 (gfx950)"
+            sha = hashlib.sha1(open(pmc, "rb").read()).hexdigest()[:12]
+            traffic_src = (f"profiles/{PMC_PROFILE} (sha1 {sha}): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command "
+                           f"(tools/make_profiles.sh), FETCH_SIZE x2 (gfx950); not re-measured inside this run")
         for name, k in kernels.items():
-            base = name.split("#")[0]
-            k["traffic"] = traffic.get(base, traffic.get(base + "9p"))  # k_channelize9p: the pruned N = 512 instantiation
+            b = name.split("#")[0]
+            k["traffic"] = traffic.get(b, traffic.get(b + "9p"))  # k_channelize9p: the pruned N = 512 instantiation
+        nch, nstreams = res["nch"], res["nstreams"]
         out = {
-            "metric": f"IQ MS/s processed (x real-time) @ {nch}ch fft_size={1 << fft_log}",
-            "value": value,
+            "metric": f"IQ MS/s processed (x real-time) @ {nch}ch fft_size={1 << res['fft_log']}",
+            "value": res["value"],
             "unit": "MS/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": {"config2": "BASELINE configs[1]: 1 device stream per GPU @ 2.56 MS/s u8 IQ, 8 AM channels, fft_size=512",
-                                    "config3": "BASELINE configs[2]: 1 device stream, 32 channels mixed AM+NFM + CTCSS, fft_size=2048",
-                                    "config4": "BASELINE configs[3]: 64 device streams x 32 mixed channels per GPU, fft_size=512",
-                                    "am64": "64 device streams x 8 AM channels per GPU, fft_size=512"}[args.workload],
-                       "streams_per_gpu": nstreams, "channels": nch, "fft_size": 1 << fft_log, "capture_seconds_per_step": nbat / 8.0,
-                       "audio_gather_to_rank0": bool(gathering), "gather_overlaps_next_step": bool(gathering),
-                       "stage2_path": "time-parallel" if h.last_path()[0] == 1 else "serial"},
-            "x_realtime_per_stream": value / world / nstreams / (SAMPLE_RATE / 1e6),
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": kernels[dom]["traffic"],
-                         "traffic_source": traffic_src,
-                         "note": "k_tp_core is the per-channel serial recurrence (one wave per channel): its time is set by VALU issue "
-                                 "latency of a lone wave, not by HBM; k_channelize is the kernel that streams the capture (see kernels)"},
+            "config": {"workload": WORKLOADS[args.workload],
+                       "streams_per_gpu": nstreams, "channels": nch, "fft_size": 1 << res["fft_log"], "capture_seconds_per_step": res["nbat"] / 8.0,
+                       "audio_gather_to_rank0": bool(res["gathering"]), "gather": gather_mode if res["gathering"] else None,
+                       "gather_overlaps_next_step": bool(res["gathering"]), "partition": "shard.stream_range (stream-major)",
+                       "stage2_path": "time-parallel" if res["path"] == 1 else "serial"},
+            "x_realtime_per_stream": res["value"] / world / nstreams / (SAMPLE_RATE / 1e6),
+            "roofline": roofline_block(res, kernels, traffic, traffic_src),
             "kernels": kernels,
         }
-        if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(pkg, dev, centre, chans, args.cpu_seconds)
+        if extra:
+            out["config5"] = extra
+        if world == 1 and args.cpu_seconds > 0 and args.workload == "config2":
+            out["cpu_baseline"] = cpu_baseline(pkg, res["dev"], res["centre"], res["chans"], args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    h.close()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -31,6 +31,13 @@ AGC_EXTRA = 100
 MOD_AM, MOD_NFM = 0, 1
 OPT_EARLY_INPUT = 1  # MI_OPT_EARLY_INPUT
 OPT_STEADY_BLOCKS = 2  # MI_OPT_STEADY_BLOCKS
+OPT_TIME_PARALLEL = 3  # result-neutral tuning switches (include/mi_airband.h)
+OPT_PRUNE_FFT = 4
+OPT_U8_CONVERSION = 5
+OPT_UNI_ROWS = 6
+OPT_TP_CHUNKS = 7
+OPT_TP_RATIO_PCT = 8
+OPT_TP_SEG_LANES = 9
 SFMT_U8, SFMT_S8, SFMT_S16, SFMT_F32 = 1, 2, 3, 4
 
 MI_OK, MI_ERR_INVALID, MI_ERR_NO_DEVICE, MI_ERR_NOMEM, MI_ERR_HIP, MI_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5

@@ -92,6 +92,15 @@ struct mi_demod {
     float2* d_cplx_last = nullptr;
     uint32_t head_off = 0;     // plane index where the AGC_EXTRA carried samples of every row live (0 after a serial call)
     bool steady_blocks = true;  // MI_OPT_STEADY_BLOCKS
+    // Tuning switches of this handle (mi_demod_set_option; defaults from the MI_AIRBAND_* environment at mi_demod_create --
+    // read per handle, the library keeps no process-wide state)
+    int opt_tp = -1;          // MI_OPT_TIME_PARALLEL: -1 auto, 0 serial kernel, 1 time-parallel whenever eligible
+    int opt_conv = -1;        // MI_OPT_U8_CONVERSION: -1 auto, 0 level table, 1 arithmetic
+    bool opt_prune = true;    // MI_OPT_PRUNE_FFT
+    int opt_uni_rows = 4096;  // MI_OPT_UNI_ROWS: up to this many rows keep one channel per wave in k_demod
+    int opt_tp_chunks = 0;    // MI_OPT_TP_CHUNKS: 0 = measured default
+    double opt_tp_ratio = 0;  // MI_OPT_TP_RATIO_PCT / 100: 0 = measured default
+    int opt_tp_lpw = 0;       // MI_OPT_TP_SEG_LANES: lanes per wave of the segment pass, 0 = auto
     bool early_input = false;  // MI_OPT_EARLY_INPUT: the IQ of a call is valid when the call is made
     bool chain_live = false;   // d_core_carry holds the chain state at the end of the previous call (it was time-parallel)
     hipStream_t seg_stream[kSegStreams] = {nullptr};  // the speculative segment passes (need core(i) only)
@@ -153,56 +162,43 @@ int n_fft_for(const mi_demod* h, int nbatches) {
     return nbatches * mi::kWaveBatch + (h->first_call ? mi::kAgcExtra : 0);
 }
 
-// MI_AIRBAND_TP=0 forces the serial kernel, =1 forces the time-parallel path whenever it is eligible
-int tp_env() {
-    const char* e = std::getenv("MI_AIRBAND_TP");
-    if (!e || !*e)
-        return -1;
-    return std::atoi(e) != 0 ? 1 : 0;
-}
 constexpr int kTpMinBatches = 8;  // below this the segments are too few to pay for the extra passes
 
-// The pruned stage-1 graph (PrunePlan, k_channelize9p) is bit-exact and about 10 % faster where it applies (N = 512, no AFC,
-// few residues among the bins): on unless MI_AIRBAND_PRUNE=0.
-// u8 conversion: the level table in LDS or the arithmetic form the plan has checked against it.  Measured on 64 streams:
-// the table is 3 % faster in the pruned N = 512 kernel, the arithmetic 1.5 % faster in the full-graph kernels: that is the
-// default; MI_AIRBAND_CONV=lut / arith forces one (A/B measurements, tests).
-int conv_choice() {  // -1 auto, 0 table, 1 arithmetic
-    static const int c = [] {
-        const char* e = std::getenv("MI_AIRBAND_CONV");
-        if (!e || !*e)
-            return -1;
-        return (e[0] == 'a' || e[0] == 'A') ? 1 : 0;
-    }();
-    return c;
-}
-bool steady_blocks_wanted() {  // MI_AIRBAND_STEADY=0: the serial stage 2 takes every step in the sample loop (A/B, tests)
-    static const bool on = [] {
-        const char* e = std::getenv("MI_AIRBAND_STEADY");
-        return !(e && *e && std::atoi(e) == 0);
-    }();
-    return on;
-}
-bool prune_wanted() {
-    static const bool on = [] {
-        const char* e = std::getenv("MI_AIRBAND_PRUNE");
-        return !(e && *e && std::atoi(e) == 0);
-    }();
-    return on;
+// Defaults of a new handle's tuning switches from the caller's environment (A/B measurements, tests):
+//   MI_AIRBAND_TP=0|1        serial kernel / time-parallel path whenever eligible
+//   MI_AIRBAND_PRUNE=0       full FFT graph at N = 512 (the pruned one is bit-exact and faster where it applies)
+//   MI_AIRBAND_CONV=lut|arith  u8 conversion through the level table / the arithmetic form the plan has checked against it
+//   MI_AIRBAND_STEADY=0      serial stage 2 takes every step in the sample loop
+//   MI_AIRBAND_UNI_ROWS=n, MI_AIRBAND_TP_CHUNKS=n, MI_AIRBAND_TP_RATIO=x, MI_AIRBAND_TP_LPW=n
+void tuning_from_env(mi_demod* h) {
+    auto get = [](const char* k) -> const char* {
+        const char* e = std::getenv(k);
+        return (e && *e) ? e : nullptr;
+    };
+    if (const char* e = get("MI_AIRBAND_TP"))
+        h->opt_tp = std::atoi(e) != 0 ? 1 : 0;
+    if (const char* e = get("MI_AIRBAND_CONV"))
+        h->opt_conv = (e[0] == 'a' || e[0] == 'A') ? 1 : 0;
+    if (const char* e = get("MI_AIRBAND_STEADY"))
+        h->steady_blocks = std::atoi(e) != 0;
+    if (const char* e = get("MI_AIRBAND_PRUNE"))
+        h->opt_prune = std::atoi(e) != 0;
+    if (const char* e = get("MI_AIRBAND_UNI_ROWS"))
+        h->opt_uni_rows = std::max(1, std::atoi(e));
+    if (const char* e = get("MI_AIRBAND_TP_CHUNKS"))
+        h->opt_tp_chunks = std::max(1, std::atoi(e));
+    if (const char* e = get("MI_AIRBAND_TP_RATIO"))
+        h->opt_tp_ratio = std::max(0.25, std::atof(e));
+    if (const char* e = get("MI_AIRBAND_TP_LPW")) {
+        const int v = std::atoi(e);
+        h->opt_tp_lpw = (v >= 1 && v <= 64) ? v : 0;
+    }
 }
 
-int lanes_per_wave_for(int rows) {
-    // up to kUniRows waves keep one channel each (the uniform instantiation of k_demod); beyond that pack lanes
-    static const int uni_rows = [] {
-        const char* e = std::getenv("MI_AIRBAND_UNI_ROWS");
-        return e ? std::max(1, std::atoi(e)) : 4096;
-    }();
-    int lpw = (rows + uni_rows - 1) / uni_rows;
-    if (lpw < 1)
-        lpw = 1;
-    if (lpw > 64)
-        lpw = 64;
-    return lpw;
+int lanes_per_wave_for(const mi_demod* h) {
+    // up to opt_uni_rows waves keep one channel each (the uniform instantiation of k_demod); beyond that pack lanes
+    int lpw = (h->rows + h->opt_uni_rows - 1) / h->opt_uni_rows;
+    return std::min(64, std::max(1, lpw));
 }
 
 // shared by both entry points; everything is enqueued on `s`
@@ -249,21 +245,21 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     ca.window = h->d_window;
     ca.tw = h->d_tw;
     ca.prune = h->plan.prune;
-    ca.prune.enabled = (ca.prune.enabled && prune_wanted()) ? 1 : 0;
+    ca.prune.enabled = (ca.prune.enabled && h->opt_prune) ? 1 : 0;
     ca.prune_t1 = h->d_prune_t1;
     ca.prune_t2 = h->d_prune_t2;
     ca.prune_rank = h->d_prune_rank;
     ca.levels = h->d_levels;
     {
         const bool pruned = ca.prune.enabled && h->plan.log2n == 9 && !h->plan.any_afc;
-        const int cc = conv_choice();
+        const int cc = h->opt_conv;
         ca.conv_arith = (h->plan.conv_arith && (cc < 0 ? !pruned : cc == 1)) ? 1 : 0;
     }
     ca.conv_scale = h->plan.conv_scale;
     ca.cp = h->d_cp;
     ca.nch = h->nch;
     ca.n_iq_rows = h->plan.n_iq_rows;
-    const int env = tp_env();
+    const int env = h->opt_tp;
     const bool use_tp = h->tp_eligible && env != 0 && (env == 1 || nbatches >= kTpMinBatches);
     ca.xmax = nullptr;  // (the time-parallel branch points it at its scratch set)
 
@@ -295,7 +291,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     da.ctcss_q = h->d_ctcss_q;
     da.stats = h->d_stats;
     da.fm_quadri = h->plan.dev.fm_quadri;
-    da.lanes_per_wave = lanes_per_wave_for(h->rows);
+    da.lanes_per_wave = lanes_per_wave_for(h);
     da.steady_blocks = h->steady_blocks ? 1 : 0;
 
     // the serial kernels expect the carried AGC_EXTRA samples of every row at the front of the planes they work on
@@ -341,10 +337,10 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         // channels 168 vs 147 GS/s)
         int want = overlap ? (h->rows <= 64 ? 1 : 2) : 3;
         double ratio = overlap ? 1.0 : 1.5;
-        if (const char* e = std::getenv("MI_AIRBAND_TP_CHUNKS"))
-            want = std::max(1, std::atoi(e));
-        if (const char* e = std::getenv("MI_AIRBAND_TP_RATIO"))
-            ratio = std::max(0.25, std::atof(e));
+        if (h->opt_tp_chunks > 0)
+            want = h->opt_tp_chunks;
+        if (h->opt_tp_ratio > 0)
+            ratio = h->opt_tp_ratio;
         std::vector<uint32_t> bound{0};  // chunk i covers units [bound[i], bound[i+1])
         if (units > 0) {
             want = std::min<int>(want, static_cast<int>(units));
@@ -408,6 +404,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.need = h->d_need;
         ta.fin = h->d_fin;
         ta.diag = h->d_diag;
+        ta.seg_lpw = h->opt_tp_lpw;
         h->last_nseg[q] = ta.nseg;
         auto chunk = [&](int i) {
             mi::TpArgs c = ta;
@@ -673,7 +670,7 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     mi_demod* h = new (std::nothrow) mi_demod();
     if (!h)
         return fail(MI_ERR_NOMEM, "host allocation failed");
-    h->steady_blocks = steady_blocks_wanted();
+    tuning_from_env(h);
     const char* msg = "";
     int rc = mi::build_plan(*dev, chans, nch, h->plan, &msg);
     if (rc != MI_OK) {
@@ -1138,6 +1135,29 @@ int mi_demod_set_option(mi_demod* h, int option, int value) {
             return MI_OK;
         case MI_OPT_STEADY_BLOCKS:
             h->steady_blocks = value != 0;
+            return MI_OK;
+        case MI_OPT_TIME_PARALLEL:
+            h->opt_tp = value < 0 ? -1 : (value != 0 ? 1 : 0);
+            return MI_OK;
+        case MI_OPT_PRUNE_FFT:
+            h->opt_prune = value != 0;
+            return MI_OK;
+        case MI_OPT_U8_CONVERSION:
+            h->opt_conv = value < 0 ? -1 : (value != 0 ? 1 : 0);
+            return MI_OK;
+        case MI_OPT_UNI_ROWS:
+            if (value < 1)
+                return fail(MI_ERR_INVALID, "MI_OPT_UNI_ROWS must be >= 1");
+            h->opt_uni_rows = value;
+            return MI_OK;
+        case MI_OPT_TP_CHUNKS:
+            h->opt_tp_chunks = std::max(0, value);
+            return MI_OK;
+        case MI_OPT_TP_RATIO_PCT:
+            h->opt_tp_ratio = value <= 0 ? 0.0 : std::max(0.25, value / 100.0);
+            return MI_OK;
+        case MI_OPT_TP_SEG_LANES:
+            h->opt_tp_lpw = (value >= 1 && value <= 64) ? value : 0;
             return MI_OK;
         default:
             return fail(MI_ERR_INVALID, "unknown option");

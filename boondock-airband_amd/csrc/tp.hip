@@ -1564,13 +1564,8 @@ hipError_t launch_tp_seg(const TpArgs& a, hipStream_t s) {
     // Lanes of one wave sit at different points of the capture, so a wave pays for every path one of its lanes takes
     // (a squelch edge costs ~9 us per block for the whole wave).  There are far fewer lanes than the 1024 SIMDs x 64
     // of the machine: spread them thin -- 4 per wave measured best at one stream x 8 channels (2 waves per SIMD) --
-    // and pack more only when the launch would exceed ~2 waves per SIMD.  MI_AIRBAND_TP_LPW overrides.
-    static const int lpw_env = [] {
-        const char* e = std::getenv("MI_AIRBAND_TP_LPW");
-        const int v = e ? std::atoi(e) : 0;
-        return (v >= 1 && v <= 64) ? v : 0;
-    }();
-    int lpw = lpw_env;
+    // and pack more only when the launch would exceed ~2 waves per SIMD.  MI_OPT_TP_SEG_LANES overrides.
+    int lpw = (a.seg_lpw >= 1 && a.seg_lpw <= 64) ? a.seg_lpw : 0;
     if (lpw == 0) {
         lpw = (lanes + 2047) / 2048;
         lpw = lpw < 4 ? 4 : (lpw > 64 ? 64 : lpw);

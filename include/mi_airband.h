@@ -182,10 +182,23 @@ int mi_demod_kernel_time_prev(mi_demod* h, int age, int index, const char** name
  * previous call (serial path; a second set of planes is allocated on first use).  Outputs still complete in stream order.
  * The audio buffer of a call must then also be free when the call is made (no reader of an earlier result still pending on
  * another stream): when it is not the buffer of the previous call, the segment passes may write it early.
- * MI_OPT_STEADY_BLOCKS (default 1, or 0 when MI_AIRBAND_STEADY=0 is in the environment): the serial stage 2 takes runs
+ * MI_OPT_STEADY_BLOCKS (default 1): the serial stage 2 takes runs
  * of steps during which the squelch stays CLOSED or OPEN 64 at a time; 0 = every step in the sample loop.  Results are
  * bit-identical either way (audio, flags, statistics, checkpoint state); the switch exists for measurements and tests. */
-enum { MI_OPT_EARLY_INPUT = 1, MI_OPT_STEADY_BLOCKS = 2 };
+enum {
+    MI_OPT_EARLY_INPUT = 1,
+    MI_OPT_STEADY_BLOCKS = 2,
+    /* Tuning switches, all result-neutral (every combination is bit-identical; they exist for measurements and tests).
+     * A handle takes its defaults from the caller's environment when it is created (MI_AIRBAND_TP, _PRUNE, _CONV=lut|arith,
+     * _STEADY, _UNI_ROWS, _TP_CHUNKS, _TP_RATIO, _TP_LPW); the library itself keeps no process-wide state. */
+    MI_OPT_TIME_PARALLEL = 3, /* -1 auto (plain AM plans, calls of >= 8 batches), 0 serial kernel, 1 whenever eligible */
+    MI_OPT_PRUNE_FFT = 4,     /* 1 (default): at N = 512 evaluate only the FFT nodes the picked bins need */
+    MI_OPT_U8_CONVERSION = 5, /* -1 auto, 0 level table in LDS, 1 arithmetic (checked against the table by the plan) */
+    MI_OPT_UNI_ROWS = 6,      /* rows (stream x channel) up to which the serial kernel keeps one channel per wave (4096) */
+    MI_OPT_TP_CHUNKS = 7,     /* chunks a time-parallel call is cut into, 0 = default */
+    MI_OPT_TP_RATIO_PCT = 8,  /* growth of consecutive chunks in percent (150 = 1.5x), 0 = default */
+    MI_OPT_TP_SEG_LANES = 9   /* lanes per wave of the segment pass, 0 = auto */
+};
 int mi_demod_set_option(mi_demod* h, int option, int value);
 
 /* ---- host-only views of the derived plan (no GPU needed; used by the CPU test-suite) ---- */

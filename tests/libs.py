@@ -2,7 +2,8 @@
 
   oracle()  -> oracle/_build/libairband_oracle.so   CPU restatement (the checker)
   ref()     -> oracle/_ref/libairband_ref.so        the reference's own squelch/ctcss/filters sources
-                                                    compiled in place (may be absent: returns None)
+                                                    compiled in place; only where /root/reference exists
+                                                    (never loaded on the GPU box: returns None there)
   product() -> boondock-airband_amd/libmi_airband.so  the C-ABI under test (include/mi_airband.h)
 
 Nothing here reads /root/reference at run time; building _ref does (oracle/Makefile `make ref`).
@@ -183,8 +184,12 @@ def oracle():
 
 
 def ref_available():
+    """The reference's own squelch/ctcss/filters build exists only where /root/reference does (the build container).
+    On the GPU box it is never probed for or loaded: there the oracle is pinned by tests/golden/components_ref.npz."""
+    if not os.path.isdir("/root/reference/src"):
+        return False
     path = os.path.join(ORACLE_DIR, "_ref", "libairband_ref.so")
-    if not os.path.exists(path) and os.path.isdir("/root/reference/src"):
+    if not os.path.exists(path):
         try:
             _make(["ref"], ORACLE_DIR)
         except Exception:

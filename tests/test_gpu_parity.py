@@ -801,3 +801,81 @@ def test_serial_calls_overlap_with_early_input(pkg, nstreams):
     for (a, b) in zip(outs[3:], outs_e):
         assert_same(b[0].cpu().numpy(), a[0].cpu().numpy(), "audio after restoring the checkpoint")
         assert_same(b[1].cpu().numpy(), a[1].cpu().numpy(), "flags after restoring the checkpoint")
+
+
+def _config4_case(pkg, nstreams, nbat):
+    """BASELINE configs[3]: `nstreams` device streams x the 32-channel config-3 plan (AM / NFM + low-pass / CTCSS / notch, four
+    channels with raw-I/Q outputs) at fft 512.  The capture of every stream is generated on the device (the bench's
+    generator, seed ^ stream id) and copied back for the oracle, so both sides see the same bytes."""
+    import torch
+    centre, chans = pkg.config3_channels()
+    for c in (1, 6, 17, 31):
+        chans[c].has_iq_outputs = 1
+    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=9)
+    nbytes = (bytes_for_batches(dev, nbat) + 255) // 256 * 256
+    # a short gate so that every stream opens and closes inside the few batches; gate phase differs per channel
+    gcfg = pkg.iqgen_cfg(sample_rate=dev.sample_rate, gate_samples=dev.sample_rate // 6,
+                         carriers=pkg.carriers_for(centre, chans, amp_q8=1024, active=lambda k: k % 4 != 2))
+    d_iq = torch.zeros((nstreams, nbytes), dtype=torch.uint8, device="cuda")
+    pkg.iqgen_device(gcfg, 0, nstreams, nbytes, 0, nbytes // 2, d_iq.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return dev, chans, d_iq, nbytes
+
+
+def _run_config4(pkg, dev, chans, d_iq, nbytes, nstreams, nbat, uni_rows=None, steady=None):
+    import torch
+    nch = len(chans)
+    d = pkg.Demod(dev, chans, nstreams=nstreams, max_batches=nbat)
+    if uni_rows is not None:
+        d.set_option(pkg.OPT_UNI_ROWS, uni_rows)
+    if steady is not None:
+        d.set_option(pkg.OPT_STEADY_BLOCKS, steady)
+    d_wo = torch.zeros((nstreams, nch, nbat * WAVE_BATCH), dtype=torch.float32, device="cuda")
+    d_ax = torch.zeros((nstreams, nch, nbat), dtype=torch.uint8, device="cuda")
+    d_zo = torch.zeros((nstreams, nch, nbat * WAVE_BATCH, 2), dtype=torch.float32, device="cuda")
+    d.process_device(d_iq.data_ptr(), nbytes, nbat, d_wo.data_ptr(), d_ax.data_ptr(), d_iq_out_ptr=d_zo.data_ptr(),
+                     hip_stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    path = d.last_path()[0]
+    d.close()
+    return d_wo.cpu().numpy(), d_ax.cpu().numpy(), d_zo.cpu().numpy(), path
+
+
+def _check_streams_against_oracle(dev, chans, iq_host, wo, ax, zo, nbat, what):
+    opened = 0
+    for st in range(iq_host.shape[0]):
+        nb, owo, oaxc, oiq = oracle_run(dev, chans, iq_host[st], nbat, want_iq=True)
+        assert nb == nbat
+        assert_same(ax[st], oaxc, f"{what}: flags, stream {st}")
+        assert_same(wo[st], owo, f"{what}: audio, stream {st}")
+        for c, ch in enumerate(chans):
+            if ch.has_iq_outputs:
+                assert_same(zo[st, c].reshape(-1), oiq[c], f"{what}: raw I/Q, stream {st} channel {c}")
+        opened += int((oaxc == ord("*")).any())
+    assert opened == iq_host.shape[0], "every stream should open some squelch in this capture"
+
+
+def test_config4_64_streams_x_32_mixed_channels_equal_the_oracle(pkg):
+    """BASELINE configs[3] at full width: 64 streams x 32 mixed channels = 2048 rows through mi_demod_process_device (one
+    channel per wave in k_demod<uni>, 2048 waves), three batches, every stream against the oracle: audio, batch flags and
+    raw I/Q on the iq channels.  Streams are independent devices (one demod thread per device in the reference,
+    rtl_airband.cpp:1044-1078), so each must equal a single-stream oracle run on its own bytes."""
+    nstreams, nbat = 64, 3
+    dev, chans, d_iq, nbytes = _config4_case(pkg, nstreams, nbat)
+    iq_host = d_iq.cpu().numpy()
+    assert not np.array_equal(iq_host[0], iq_host[1]), "streams carry different noise"
+    wo, ax, zo, path = _run_config4(pkg, dev, chans, d_iq, nbytes, nstreams, nbat)
+    assert path == 0
+    _check_streams_against_oracle(dev, chans, iq_host, wo, ax, zo, nbat, "config4")
+
+
+@pytest.mark.parametrize("uni_rows,nstreams", [(1, 3), (16, 3), (64, 64)])
+def test_lane_packed_k_demod_equals_the_oracle(pkg, uni_rows, nstreams):
+    """Above MI_OPT_UNI_ROWS rows the serial kernel packs several channels into the lanes of a wave (k_demod<false>: its own
+    row / lane mapping, no steady blocks, CTCSS per lane).  Forced here on the config-3 plan: 96 rows at 64 lanes per wave and
+    at 6 lanes per wave, and the whole configs[3] width (2048 rows) at 32 lanes per wave; every stream equals the oracle."""
+    nbat = 3 if nstreams <= 3 else 2
+    dev, chans, d_iq, nbytes = _config4_case(pkg, nstreams, nbat)
+    iq_host = d_iq.cpu().numpy()
+    wo, ax, zo, _ = _run_config4(pkg, dev, chans, d_iq, nbytes, nstreams, nbat, uni_rows=uni_rows)
+    _check_streams_against_oracle(dev, chans, iq_host, wo, ax, zo, nbat, f"lane-packed, uni_rows {uni_rows}")
