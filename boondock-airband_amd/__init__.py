@@ -38,6 +38,8 @@ OPT_UNI_ROWS = 6
 OPT_TP_CHUNKS = 7
 OPT_TP_RATIO_PCT = 8
 OPT_TP_SEG_LANES = 9
+OPT_LANE_FFT = 10
+OPT_LANE_FFT_JIT = 11
 SFMT_U8, SFMT_S8, SFMT_S16, SFMT_F32 = 1, 2, 3, 4
 
 MI_OK, MI_ERR_INVALID, MI_ERR_NO_DEVICE, MI_ERR_NOMEM, MI_ERR_HIP, MI_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
@@ -92,7 +94,7 @@ class MixInput(C.Structure):  # mi_mix_input
 ABI_SYMBOLS = [
     "mi_last_error", "mi_device_count", "mi_demod_create", "mi_demod_destroy", "mi_demod_bytes_needed", "mi_demod_bytes_consumed",
     "mi_demod_hop_bytes", "mi_demod_process", "mi_demod_process_device", "mi_demod_get_stats", "mi_demod_state_size",
-    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_tp_debug", "mi_demod_kernel_time", "mi_demod_kernel_time_prev", "mi_demod_set_option", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
+    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_last_stage1", "mi_demod_tp_debug", "mi_demod_kernel_time", "mi_demod_kernel_time_prev", "mi_demod_set_option", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
     "mi_plan_window", "mi_plan_twiddles", "mi_plan_levels", "mi_plan_sincos_lut", "mi_plan_channel", "mi_plan_ctcss_coeffs",
     "mi_iqgen_host", "mi_iqgen_device", "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_is_stereo", "mi_mixer_process_device",
 ]
@@ -112,6 +114,7 @@ def lib():
         L.mi_device_count.restype = C.c_int
         L.mi_demod_create.argtypes = [C.POINTER(DeviceCfg), C.POINTER(ChannelCfg), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.mi_demod_destroy.argtypes = [vp]
+        L.mi_demod_last_stage1.argtypes = [vp, C.POINTER(C.c_int)]
         L.mi_demod_destroy.restype = None
         for f in (L.mi_demod_bytes_needed, L.mi_demod_bytes_consumed):
             f.argtypes = [vp, C.c_int]
@@ -291,6 +294,12 @@ class Demod:
         a, b = C.c_int(0), C.c_int(0)
         _check(lib().mi_demod_last_path(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def last_stage1(self):
+        """MI_STAGE1_* of the last call: 0 / 1 exchange kernels (full / pruned), 2 / 3 lane-resident (full graph / plan-compiled)."""
+        k = C.c_int(-1)
+        _check(lib().mi_demod_last_stage1(self._h, C.byref(k)))
+        return k.value
 
     def tp_debug(self, row):
         """(core[nseg+1][4], diag[4]) of the last time-parallel call for one row."""

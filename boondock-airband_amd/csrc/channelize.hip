@@ -572,7 +572,9 @@ hipError_t launch_fmt(const ChannelizeArgs& a, int sfmt, int nstreams, hipStream
 hipError_t launch_channelize(const ChannelizeArgs& a, int log2n, int sfmt, int nstreams, hipStream_t s) {
     if (a.nfft == 0 || nstreams == 0)
         return hipSuccess;
-    // the pruned graph has no complete spectrum: AFC launches (they want one) take the full kernel
+    // the pruned graphs have no complete spectrum: AFC launches (they want one) take the full kernel
+    if (log2n == 9 && a.l64.enabled && a.l64_chan && !a.afc_spec && !a.st)
+        return launch_channelize_l64(a, sfmt, nstreams, s);
     if (log2n == 9 && a.prune.enabled && a.prune_t1 && a.prune_t2 && a.prune_rank && !a.afc_spec && !a.st) {
         switch (sfmt) {
             case MI_SFMT_U8: return a.conv_arith ? launch_9p<kSfmtU8Arith>(a, nstreams, s) : launch_9p<MI_SFMT_U8>(a, nstreams, s);

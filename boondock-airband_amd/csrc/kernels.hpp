@@ -65,6 +65,10 @@ struct ChannelizeArgs {
     const float* prune_t1;    // its item-class tables of pass 1 / pass 2 (kPruneClassWords floats per class)
     const float* prune_t2;
     const int* prune_rank;    // [nch] rank of each channel's bin among the distinct picked bins
+    L64Plan l64;                   // lane-resident stage 1 (l64_kernel.h); l64.enabled selects it
+    const L64Chan* l64_chan;       // [nch] for the plan's own instance
+    const L64Chan* l64_chan_full;  // [nch] for the full-graph instance
+    const struct L64Jit* l64_jit;  // the plan's own instance (l64_jit.cpp), or null: the full-graph instance runs
     const ChanState* st;  // AFC handles: the bin of (stream, channel) is st[..].afc_bin; null: ChanParams::bin
     float* afc_spec;      // AFC handles: [nstreams][fft_size] re^2+im^2 of the LAST window of the launch (AFC::square), or null
 };
@@ -178,6 +182,15 @@ constexpr int TP_REST_MARKS = 3;  // marks (optional): after scan#0, after fix#0
 
 
 hipError_t launch_channelize(const ChannelizeArgs& a, int log2n, int sfmt, int nstreams, hipStream_t s);
+// channelize_l64.hip: the lane-resident N = 512 kernel (launch_channelize takes it when a.l64.enabled)
+bool l64_supported(int log2n, size_t hop_bytes, int bytes_per_sample);
+hipError_t launch_channelize_l64(const ChannelizeArgs& a, int sfmt, int nstreams, hipStream_t s);
+int l64_round_windows(int m6);
+int l64_zstride(int m6);
+// l64_jit.cpp: the kernel compiled for one plan's masks by hipRTC (cached per (device, hop, masks) for the life of the process;
+// null when hipRTC is missing or the compilation fails -- `why` then says so)
+const L64Jit* l64_jit_get(int device, int hop, const uint64_t need[6], const char** why);
+hipError_t l64_jit_launch(const L64Jit* j, const L64Args& a, unsigned gx, unsigned gy, size_t lds, hipStream_t s);
 hipError_t launch_demod(const DemodArgs& a, hipStream_t s);
 hipError_t launch_init_state(ChanState* st, float* carry, float* sq_ring, float* ctcss_q, const ChanParams* cp, int nstreams, int nch,
                              int n_ctcss_rows, hipStream_t s);

@@ -1,0 +1,192 @@
+// l64_jit.cpp -- run-time compilation of the lane-resident stage-1 kernel (l64_kernel.h) for one channel plan.
+//
+// The FFT graph a plan needs is known when its handle is created: which residues { bin mod 2^s } are live after each of
+// the first six stages.  With those masks as compile-time constants the kernel is straight-line code holding exactly the
+// plan's butterflies (for the 8-channel plan of BASELINE configs[1]: 152 of the 384 output halves, most of them plain adds).
+// hipRTC compiles the same source text hipcc compiles ahead of time for the full graph (embedded below by the Makefile),
+// the code object is loaded with the module API and kept for the life of the process, keyed by (device, hop, masks).
+// hipRTC is looked up with dlopen: the library has no link-time dependency on it, and where it is missing, or the
+// compilation fails, the caller runs the ahead-of-time full-graph instance instead.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace mi {
+
+struct L64Jit {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    size_t lds_attr = 0;  // dynamic LDS size the function has been told about
+};
+
+namespace {
+
+const char kL64Source[] =
+#include "build/l64_src.inc"
+    ;
+
+// the few hipRTC entry points used, resolved at run time
+struct Rtc {
+    void* lib = nullptr;
+    int (*create)(void**, const char*, const char*, int, const char**, const char**) = nullptr;
+    int (*compile)(void*, int, const char**) = nullptr;
+    int (*log_size)(void*, size_t*) = nullptr;
+    int (*get_log)(void*, char*) = nullptr;
+    int (*code_size)(void*, size_t*) = nullptr;
+    int (*get_code)(void*, char*) = nullptr;
+    int (*destroy)(void**) = nullptr;
+    bool ok = false;
+};
+
+Rtc& rtc() {
+    static Rtc r = [] {
+        Rtc x;
+        for (const char* name : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) {
+            x.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (x.lib)
+                break;
+        }
+        if (!x.lib)
+            return x;
+        auto sym = [&](const char* n) { return dlsym(x.lib, n); };
+        x.create = reinterpret_cast<decltype(x.create)>(sym("hiprtcCreateProgram"));
+        x.compile = reinterpret_cast<decltype(x.compile)>(sym("hiprtcCompileProgram"));
+        x.log_size = reinterpret_cast<decltype(x.log_size)>(sym("hiprtcGetProgramLogSize"));
+        x.get_log = reinterpret_cast<decltype(x.get_log)>(sym("hiprtcGetProgramLog"));
+        x.code_size = reinterpret_cast<decltype(x.code_size)>(sym("hiprtcGetCodeSize"));
+        x.get_code = reinterpret_cast<decltype(x.get_code)>(sym("hiprtcGetCode"));
+        x.destroy = reinterpret_cast<decltype(x.destroy)>(sym("hiprtcDestroyProgram"));
+        x.ok = x.create && x.compile && x.log_size && x.get_log && x.code_size && x.get_code && x.destroy;
+        return x;
+    }();
+    return r;
+}
+
+struct Key {
+    int device, hop;
+    uint64_t need[6];
+    bool operator<(const Key& o) const {
+        if (device != o.device)
+            return device < o.device;
+        if (hop != o.hop)
+            return hop < o.hop;
+        return std::memcmp(need, o.need, sizeof(need)) < 0;
+    }
+};
+struct Entry {
+    L64Jit jit;
+    bool usable = false;
+    std::string why;
+};
+std::mutex g_mu;
+std::map<Key, Entry*> g_cache;  // entries live until the process ends (their modules too)
+
+}  // namespace
+
+const L64Jit* l64_jit_get(int device, int hop, const uint64_t need[6], const char** why) {
+    static const char* none = "";
+    if (why)
+        *why = none;
+    Key k{};
+    k.device = device;
+    k.hop = hop;
+    std::memcpy(k.need, need, sizeof(k.need));
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_cache.find(k);
+    if (it != g_cache.end()) {
+        if (why)
+            *why = it->second->why.c_str();
+        return it->second->usable ? &it->second->jit : nullptr;
+    }
+    Entry* e = new Entry();
+    g_cache[k] = e;
+    auto fail = [&](const std::string& msg) -> const L64Jit* {
+        e->why = msg;
+        if (std::getenv("MI_AIRBAND_DEBUG"))
+            std::fprintf(stderr, "mi_airband: lane-resident stage 1 not compiled for this plan (%s); the full-graph instance runs\n", msg.c_str());
+        if (why)
+            *why = e->why.c_str();
+        return nullptr;
+    };
+    Rtc& r = rtc();
+    if (!r.ok)
+        return fail("hipRTC not available");
+    void* prog = nullptr;
+    if (r.create(&prog, kL64Source, "l64_kernel.hip", 0, nullptr, nullptr) != 0 || !prog)
+        return fail("hiprtcCreateProgram failed");
+    hipDeviceProp_t prop{};
+    std::string arch = "gfx950";
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.gcnArchName[0])
+        arch = prop.gcnArchName;
+    std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-DMI_L64_JIT=1",
+                                     "-DL64_HOP=" + std::to_string(hop), "-DL64_MINWAVES=2"};
+    for (int s = 0; s < 6; ++s) {
+        char buf[64];
+        std::snprintf(buf, sizeof(buf), "-DL64_N%d=0x%llxull", s + 1, static_cast<unsigned long long>(need[s]));
+        opts.push_back(buf);
+    }
+    std::vector<const char*> copts;
+    for (const std::string& o : opts)
+        copts.push_back(o.c_str());
+    const int rc = r.compile(prog, static_cast<int>(copts.size()), copts.data());
+    if (rc != 0) {
+        size_t n = 0;
+        std::string log;
+        if (r.log_size(prog, &n) == 0 && n > 1) {
+            log.resize(n);
+            r.get_log(prog, log.data());
+        }
+        r.destroy(&prog);
+        return fail("hiprtcCompileProgram failed: " + log.substr(0, 2000));
+    }
+    size_t csz = 0;
+    if (r.code_size(prog, &csz) != 0 || csz == 0) {
+        r.destroy(&prog);
+        return fail("hiprtcGetCodeSize failed");
+    }
+    std::vector<char> code(csz);
+    const int gc = r.get_code(prog, code.data());
+    r.destroy(&prog);
+    if (gc != 0)
+        return fail("hiprtcGetCode failed");
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != device && hipSetDevice(device) != hipSuccess)
+        return fail("hipSetDevice failed");
+    hipError_t he = hipModuleLoadData(&e->jit.mod, code.data());
+    if (he == hipSuccess)
+        he = hipModuleGetFunction(&e->jit.fn, e->jit.mod, "l64_entry");
+    if (cur != device)
+        (void)hipSetDevice(cur);
+    if (he != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(std::string("loading the compiled kernel failed: ") + hipGetErrorString(he));
+    }
+    e->usable = true;
+    return &e->jit;
+}
+
+hipError_t l64_jit_launch(const L64Jit* j, const L64Args& a, unsigned gx, unsigned gy, size_t lds, hipStream_t s) {
+    L64Jit* m = const_cast<L64Jit*>(j);
+    if (lds > 48 * 1024 && lds > m->lds_attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(m->fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess)
+            (void)hipGetLastError();  // (not every runtime wants it for module functions: the launch below decides)
+        m->lds_attr = lds;
+    }
+    L64Args args = a;
+    size_t sz = sizeof(args);
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(m->fn, gx, gy, 1, 256, 1, 1, static_cast<unsigned>(lds), s, nullptr, cfg);
+}
+
+}  // namespace mi

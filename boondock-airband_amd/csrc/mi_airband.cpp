@@ -101,6 +101,9 @@ struct mi_demod {
     int opt_tp_chunks = 0;    // MI_OPT_TP_CHUNKS: 0 = measured default
     double opt_tp_ratio = 0;  // MI_OPT_TP_RATIO_PCT / 100: 0 = measured default
     int opt_tp_lpw = 0;       // MI_OPT_TP_SEG_LANES: lanes per wave of the segment pass, 0 = auto
+    bool opt_l64 = true;      // MI_OPT_LANE_FFT: the lane-resident stage 1 at N = 512 where the plan allows it
+    int opt_l64_linear = 0;   // (diagnostic) tiles in blockIdx order instead of grouped per XCD
+    bool opt_l64_jit = true;  // MI_OPT_LANE_FFT_JIT: compile the plan's own instance with hipRTC (else the full-graph instance)
     bool early_input = false;  // MI_OPT_EARLY_INPUT: the IQ of a call is valid when the call is made
     bool chain_live = false;   // d_core_carry holds the chain state at the end of the previous call (it was time-parallel)
     hipStream_t seg_stream[kSegStreams] = {nullptr};  // the speculative segment passes (need core(i) only)
@@ -118,6 +121,11 @@ struct mi_demod {
     float* d_prune_t1 = nullptr;  // stage-1 pruning tables (plan.prune)
     float* d_prune_t2 = nullptr;
     int* d_prune_rank = nullptr;
+    L64Chan* d_l64_chan = nullptr;       // per-channel tables of the lane-resident stage 1 (plan.l64): the plan's own instance,
+    L64Chan* d_l64_chan_full = nullptr;  // the full-graph instance
+    const mi::L64Jit* l64_jit = nullptr; // the kernel compiled for this plan's masks (owned by the process-wide cache), or null
+    bool l64_jit_tried = false;
+    int last_stage1 = 0;  // MI_STAGE1_* of the last call
     float* d_levels = nullptr;
     float* d_sin = nullptr;
     float* d_cos = nullptr;
@@ -169,6 +177,7 @@ constexpr int kTpMinBatches = 8;  // below this the segments are too few to pay 
 //   MI_AIRBAND_PRUNE=0       full FFT graph at N = 512 (the pruned one is bit-exact and faster where it applies)
 //   MI_AIRBAND_CONV=lut|arith  u8 conversion through the level table / the arithmetic form the plan has checked against it
 //   MI_AIRBAND_STEADY=0      serial stage 2 takes every step in the sample loop
+//   MI_AIRBAND_L64=0         no lane-resident stage 1 at N = 512 (the pruned / full exchange kernels instead)
 //   MI_AIRBAND_UNI_ROWS=n, MI_AIRBAND_TP_CHUNKS=n, MI_AIRBAND_TP_RATIO=x, MI_AIRBAND_TP_LPW=n
 void tuning_from_env(mi_demod* h) {
     auto get = [](const char* k) -> const char* {
@@ -189,6 +198,12 @@ void tuning_from_env(mi_demod* h) {
         h->opt_tp_chunks = std::max(1, std::atoi(e));
     if (const char* e = get("MI_AIRBAND_TP_RATIO"))
         h->opt_tp_ratio = std::max(0.25, std::atof(e));
+    if (const char* e = get("MI_AIRBAND_L64"))
+        h->opt_l64 = std::atoi(e) != 0;
+    if (const char* e = get("MI_AIRBAND_L64_JIT"))
+        h->opt_l64_jit = std::atoi(e) != 0;
+    if (const char* e = get("MI_AIRBAND_L64_WGS"))
+        h->opt_l64_linear = std::max(0, std::atoi(e));
     if (const char* e = get("MI_AIRBAND_TP_LPW")) {
         const int v = std::atoi(e);
         h->opt_tp_lpw = (v >= 1 && v <= 64) ? v : 0;
@@ -249,6 +264,22 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     ca.prune_t1 = h->d_prune_t1;
     ca.prune_t2 = h->d_prune_t2;
     ca.prune_rank = h->d_prune_rank;
+    ca.l64 = h->plan.l64;
+    ca.l64.enabled = (ca.l64.enabled && h->opt_l64 && h->d_l64_chan) ? 1 : 0;
+    ca.l64.linear_tiles = 0;
+    ca.l64.wg_per_cu = h->opt_l64_linear;  // (MI_AIRBAND_L64_WGS: workgroups per CU of the persistent stage-1 launch, 0 = default)
+    ca.l64_chan = h->d_l64_chan;
+    ca.l64_chan_full = h->d_l64_chan_full;
+    if (ca.l64.enabled && !h->l64_jit_tried && h->opt_l64_jit) {  // (on first use: a handle that never runs stage 1 this way compiles nothing)
+        h->l64_jit_tried = true;
+        const int hop = static_cast<int>(h->plan.hop_bytes / (2 * static_cast<size_t>(h->plan.bytes_per_sample)));
+        h->l64_jit = mi::l64_jit_get(h->gpu, hop, h->plan.l64.need, nullptr);
+    }
+    ca.l64_jit = h->opt_l64_jit ? h->l64_jit : nullptr;
+    // The prebuilt full-graph instance keeps all 64 points of a lane live and is slower than the exchange kernels: it runs
+    // only when asked for (MI_OPT_LANE_FFT_JIT = 0, tests); without hipRTC the pruned / full exchange kernels take over.
+    if (ca.l64.enabled && h->opt_l64_jit && !ca.l64_jit)
+        ca.l64.enabled = 0;
     ca.levels = h->d_levels;
     {
         const bool pruned = ca.prune.enabled && h->plan.log2n == 9 && !h->plan.any_afc;
@@ -259,6 +290,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     ca.cp = h->d_cp;
     ca.nch = h->nch;
     ca.n_iq_rows = h->plan.n_iq_rows;
+    h->last_stage1 = (ca.l64.enabled && h->plan.log2n == 9 && !h->plan.any_afc) ? (ca.l64_jit ? MI_STAGE1_LANE_PLAN : MI_STAGE1_LANE_FULL)
+                     : ((ca.prune.enabled && h->plan.log2n == 9 && !h->plan.any_afc) ? MI_STAGE1_EXCHANGE_PRUNED : MI_STAGE1_EXCHANGE_FULL);
     const int env = h->opt_tp;
     const bool use_tp = h->tp_eligible && env != 0 && (env == 1 || nbatches >= kTpMinBatches);
     ca.xmax = nullptr;  // (the time-parallel branch points it at its scratch set)
@@ -621,7 +654,7 @@ void mi_demod_destroy(mi_demod* h) {
         return;
     (void)hipSetDevice(h->gpu);
     (void)hipDeviceSynchronize();  // calls may still be in flight on the handle's own streams
-    void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_t1, h->d_prune_t2, h->d_prune_rank, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx_set[0], h->d_cplx_set[1], h->d_carry,
+    void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_t1, h->d_prune_t2, h->d_prune_rank, h->d_l64_chan, h->d_l64_chan_full, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx_set[0], h->d_cplx_set[1], h->d_carry,
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc,
                     h->d_rows,   h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_fullbound, h->d_afc_spec};
     for (void* p : ptrs)
@@ -753,6 +786,12 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
         TRY_OR_BAIL(hipMemcpy(h->d_prune_t2, p.prune_t2.data(), p.prune_t2.size() * 4, hipMemcpyHostToDevice));
         TRY_OR_BAIL(dalloc(&h->d_prune_rank, p.prune_chan_rank.size()));
         TRY_OR_BAIL(hipMemcpy(h->d_prune_rank, p.prune_chan_rank.data(), p.prune_chan_rank.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (p.l64.enabled) {
+        TRY_OR_BAIL(dalloc(&h->d_l64_chan, p.l64_chan.size()));
+        TRY_OR_BAIL(hipMemcpy(h->d_l64_chan, p.l64_chan.data(), p.l64_chan.size() * sizeof(L64Chan), hipMemcpyHostToDevice));
+        TRY_OR_BAIL(dalloc(&h->d_l64_chan_full, p.l64_chan_full.size()));
+        TRY_OR_BAIL(hipMemcpy(h->d_l64_chan_full, p.l64_chan_full.data(), p.l64_chan_full.size() * sizeof(L64Chan), hipMemcpyHostToDevice));
     }
     TRY_OR_BAIL(hipMemcpy(h->d_levels, p.levels.data(), 256 * 4, hipMemcpyHostToDevice));
     TRY_OR_BAIL(hipMemcpy(h->d_sin, p.sin_lut, 257 * 4, hipMemcpyHostToDevice));
@@ -1010,6 +1049,13 @@ int mi_demod_last_path(mi_demod* h, int* time_parallel, int* unverified_rows) {
     return MI_OK;
 }
 
+int mi_demod_last_stage1(mi_demod* h, int* kind) {
+    if (!h || !kind)
+        return fail(MI_ERR_INVALID, "NULL argument");
+    *kind = h->last_stage1;
+    return MI_OK;
+}
+
 int mi_demod_tp_debug(mi_demod* h, int row, float* core4, int max_entries, int* diag4, int* nseg) {
     if (!h || row < 0 || row >= h->rows || !h->tp_eligible || h->last_path != 1)
         return fail(MI_ERR_INVALID, "the last call did not take the time-parallel path");
@@ -1158,6 +1204,12 @@ int mi_demod_set_option(mi_demod* h, int option, int value) {
             return MI_OK;
         case MI_OPT_TP_SEG_LANES:
             h->opt_tp_lpw = (value >= 1 && value <= 64) ? value : 0;
+            return MI_OK;
+        case MI_OPT_LANE_FFT:
+            h->opt_l64 = value != 0;
+            return MI_OK;
+        case MI_OPT_LANE_FFT_JIT:
+            h->opt_l64_jit = value != 0;
             return MI_OK;
         default:
             return fail(MI_ERR_INVALID, "unknown option");

@@ -351,6 +351,51 @@ int build_plan(const mi_device_cfg& dev, const mi_channel_cfg* chans, int nch, P
             pr.enabled = (pr.m3 * 8 + pr.m6 <= 64 && pr.m9 < 255) ? 1 : 0;
         }
     }
+    // ---- lane-resident stage 1 (see L64Plan) ----
+    {
+        L64Plan& lp = p.l64;
+        lp = L64Plan{};
+        p.l64_chan.clear();
+        p.l64_chan_full.clear();
+        static const float kTwLit[256][2] = {
+#include "tw512.inc"
+        };
+        bool lits_ok = p.fft_size == 512;
+        for (size_t k = 0; lits_ok && k < 256; ++k)  // the kernel's literal twiddles must be the spec's table, bit for bit
+            lits_ok = std::memcmp(&kTwLit[k][0], &p.tw[2 * k], 4) == 0 && std::memcmp(&kTwLit[k][1], &p.tw[2 * k + 1], 4) == 0;
+        const size_t hop = p.hop_bytes / (2 * static_cast<size_t>(p.bytes_per_sample));
+        if (lits_ok && !p.any_afc && nch <= 64 && (hop == 160 || hop == 128)) {
+            for (int s = 1; s <= 6; ++s)
+                for (const ChanParams& c : p.cp)
+                    lp.need[s - 1] |= 1ull << (c.bin & ((1u << s) - 1u));
+            lp.m6 = __builtin_popcountll(lp.need[5]);
+            lp.nb_pad = 8;
+            while (lp.nb_pad < nch)
+                lp.nb_pad *= 2;
+            auto tw_signed = [&](unsigned bin, int s, float& x, float& y) {  // stage s = 7, 8, 9: W_{2^s}^{bin mod 2^(s-1)}, negated for an upper output
+                const unsigned half = 1u << (s - 1);
+                const unsigned e = (bin & (half - 1u)) * (512u >> s);
+                x = p.tw[2 * e], y = p.tw[2 * e + 1];
+                if (bin & half)
+                    x = -x, y = -y;
+            };
+            p.l64_chan.resize(static_cast<size_t>(nch));
+            for (int i = 0; i < nch; ++i) {
+                const ChanParams& c = p.cp[static_cast<size_t>(i)];
+                L64Chan& o = p.l64_chan[static_cast<size_t>(i)];
+                const unsigned cls = c.bin & 63u;
+                o.slot = __builtin_popcountll(lp.need[5] & ((1ull << cls) - 1ull));
+                o.iq_row = c.iq_row;
+                tw_signed(c.bin, 7, o.w7x, o.w7y);
+                tw_signed(c.bin, 8, o.w8x, o.w8y);
+                tw_signed(c.bin, 9, o.w9x, o.w9y);
+            }
+            p.l64_chan_full = p.l64_chan;
+            for (int i = 0; i < nch; ++i)
+                p.l64_chan_full[static_cast<size_t>(i)].slot = static_cast<int>(p.cp[static_cast<size_t>(i)].bin & 63u);
+            lp.enabled = 1;
+        }
+    }
     return MI_OK;
 }
 

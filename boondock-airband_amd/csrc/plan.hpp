@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/mi_airband.h"
+#include "l64_args.h"
 
 namespace mi {
 
@@ -61,6 +62,18 @@ struct PrunePlan {
 // 2 unused.
 constexpr int kPruneClassWords = 24;
 
+// The lane-resident stage 1 (l64_kernel.h, N = 512): which residues { bin mod 2^s } are live after stage s = 1..6
+// (bit r of need[s-1]).  L64Chan (l64_args.h) tells the combining step where a channel's class sits and which twiddles
+// lead to its bin.
+struct L64Plan {
+    int32_t enabled;
+    int32_t m6;            // live classes mod 64
+    int32_t nb_pad;        // channels per window padded to a power of two, 8 .. 64
+    int32_t linear_tiles;  // (unused)
+    int32_t wg_per_cu;     // (tuning, set by the caller) workgroups launched per CU, 0 = default
+    uint64_t need[6];
+};
+
 struct Plan {
     mi_device_cfg dev{};
     std::vector<mi_channel_cfg> chans;
@@ -84,6 +97,9 @@ struct Plan {
     std::vector<float> prune_t1;      // (1 << sh3) classes x kPruneClassWords
     std::vector<float> prune_t2;      // (1 << sh6) classes x kPruneClassWords
     std::vector<int32_t> prune_chan_rank;  // per channel: rank of its bin among the distinct picked bins
+    L64Plan l64{};                    // lane-resident stage 1 (N = 512, no AFC, hop a supported multiple of 8, <= 64 channels)
+    std::vector<L64Chan> l64_chan;       // nch: slots among the plan's live classes (the plan's own kernel instance)
+    std::vector<L64Chan> l64_chan_full;  // nch: slot = bin mod 64 (the full-graph instance)
     float initial_noise_floor = 5.0f;
 };
 

@@ -146,6 +146,12 @@ int mi_demod_set_state(mi_demod* h, const void* buf, size_t len);
  * the tests can assert that.  Synchronises. */
 int mi_demod_last_path(mi_demod* h, int* time_parallel, int* unverified_rows);
 
+/* Which stage-1 kernel the last call ran (diagnostic; every one of them yields the same bits): the radix-8 exchange kernels
+ * (full graph, or pruned to the picked bins at N = 512), or the lane-resident N = 512 kernel (prebuilt full graph, or compiled
+ * for this plan's own FFT nodes by hipRTC -- MI_OPT_LANE_FFT / MI_OPT_LANE_FFT_JIT). */
+enum { MI_STAGE1_EXCHANGE_FULL = 0, MI_STAGE1_EXCHANGE_PRUNED = 1, MI_STAGE1_LANE_FULL = 2, MI_STAGE1_LANE_PLAN = 3 };
+int mi_demod_last_stage1(mi_demod* h, int* kind);
+
 /* Diagnostics of the time-parallel path after a call that took it (synchronises): the exact Squelch core
  * state {noise_floor_, moving_avg_cap_, pre_filter_.capped_, pre_filter_.full_} before each 512-step segment
  * (core4: [nseg+1][4]) and diag8[0..3] = segments not accepted in verification scans 0..3 (scan 3 runs after the
@@ -189,7 +195,7 @@ enum {
     MI_OPT_EARLY_INPUT = 1,
     MI_OPT_STEADY_BLOCKS = 2,
     /* Tuning switches, all result-neutral (every combination is bit-identical; they exist for measurements and tests).
-     * A handle takes its defaults from the caller's environment when it is created (MI_AIRBAND_TP, _PRUNE, _CONV=lut|arith,
+     * A handle takes its defaults from the caller's environment when it is created (MI_AIRBAND_TP, _PRUNE, _L64, _L64_JIT, _CONV=lut|arith,
      * _STEADY, _UNI_ROWS, _TP_CHUNKS, _TP_RATIO, _TP_LPW); the library itself keeps no process-wide state. */
     MI_OPT_TIME_PARALLEL = 3, /* -1 auto (plain AM plans, calls of >= 8 batches), 0 serial kernel, 1 whenever eligible */
     MI_OPT_PRUNE_FFT = 4,     /* 1 (default): at N = 512 evaluate only the FFT nodes the picked bins need */
@@ -197,7 +203,10 @@ enum {
     MI_OPT_UNI_ROWS = 6,      /* rows (stream x channel) up to which the serial kernel keeps one channel per wave (4096) */
     MI_OPT_TP_CHUNKS = 7,     /* chunks a time-parallel call is cut into, 0 = default */
     MI_OPT_TP_RATIO_PCT = 8,  /* growth of consecutive chunks in percent (150 = 1.5x), 0 = default */
-    MI_OPT_TP_SEG_LANES = 9   /* lanes per wave of the segment pass, 0 = auto */
+    MI_OPT_TP_SEG_LANES = 9,  /* lanes per wave of the segment pass, 0 = auto */
+    MI_OPT_LANE_FFT = 10,     /* 1 (default): at N = 512 the first six FFT stages stay in the lanes (l64_kernel.h) where the plan allows */
+    MI_OPT_LANE_FFT_JIT = 11  /* 1 (default): that kernel is compiled for the plan's own FFT nodes by hipRTC on first use (the code object is
+                               * cached per (device, hop, masks) for the life of the process); 0, or hipRTC missing: the prebuilt full graph */
 };
 int mi_demod_set_option(mi_demod* h, int option, int value);
 

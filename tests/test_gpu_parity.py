@@ -563,42 +563,100 @@ def test_checkpoint_between_overlapping_calls_and_timing_ages(pkg, monkeypatch):
     assert_same(rest_b[0][1].cpu().numpy(), rest_a[0][1].cpu().numpy(), "flags after restoring the checkpoint")
 
 
-def test_stage1_alternative_instantiations_keep_every_bit(pkg, tmp_path):
-    """By default stage 1 evaluates, at N = 512, only the nodes of the radix-2 graph that feed the picked bins (PrunePlan) and
-    takes u8 samples through the level table there (arithmetically in the full-graph kernels); every other test here runs that
-    way.  MI_AIRBAND_PRUNE=0 with MI_AIRBAND_CONV=lut, and MI_AIRBAND_CONV=arith with the pruned graph, select the other
-    combinations: any subset of the graph is computed with the same operations and the conversion is
-    checked against the table value by value, so audio and raw I/Q stay bit-exact.  Fresh process: the switches are read once."""
-    import subprocess
-    import sys
-    import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, os\n"
-        f"sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
-        "import numpy as np\n"
-        "from conftest import load_package\n"
-        "from common import gen_iq, oracle_run, WAVE_BATCH\n"
-        "pkg = load_package()\n"
-        "for name in ('config2', 'config3'):\n"
-        "    centre, chans = getattr(pkg, name + '_channels')()\n"
-        "    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=9)\n"
-        "    nbat = 6\n"
-        "    kw = {} if name == 'config2' else dict(amp_q8=1024, active=lambda k: k % 4 != 2)\n"
-        "    iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=2, **kw)\n"
-        "    d = pkg.Demod(dev, chans, max_batches=nbat)\n"
-        "    wo, axc, iqo, _ = d.process([iq], nbat, want_iq=True)\n"
-        "    d.close()\n"
-        "    nb, owo, oaxc, oiq = oracle_run(dev, chans, iq, nbat, want_iq=True)\n"
-        "    assert np.array_equal(wo[0, :, :nbat * WAVE_BATCH], owo) and np.array_equal(axc[0], oaxc), name\n"
-        "    for c, ch in enumerate(chans):\n"
-        "        if ch.has_iq_outputs:\n"
-        "            assert np.array_equal(iqo[0, c].reshape(-1), oiq[c]), (name, c)\n"
-        "print('stage1 ok')\n")
-    for extra in (dict(MI_AIRBAND_PRUNE="0", MI_AIRBAND_CONV="lut"), dict(MI_AIRBAND_CONV="arith")):
-        env = dict(os.environ, **extra)
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
-        assert r.returncode == 0 and "stage1 ok" in r.stdout, r.stdout + r.stderr
+STAGE1_VARIANTS = {
+    # name: (options, the MI_STAGE1_* kind the handle must report at N = 512)
+    "lane-resident, compiled for the plan (default)": ({}, 3),
+    "lane-resident, prebuilt full graph": ({"OPT_LANE_FFT_JIT": 0}, 2),
+    "exchange kernel, pruned graph, level table": ({"OPT_LANE_FFT": 0}, 1),
+    "exchange kernel, pruned graph, arithmetic conversion": ({"OPT_LANE_FFT": 0, "OPT_U8_CONVERSION": 1}, 1),
+    "exchange kernel, full graph, level table": ({"OPT_LANE_FFT": 0, "OPT_PRUNE_FFT": 0, "OPT_U8_CONVERSION": 0}, 0),
+}
+
+
+@pytest.mark.parametrize("variant", list(STAGE1_VARIANTS))
+def test_stage1_alternative_instantiations_keep_every_bit(pkg, variant):
+    """Stage 1 at N = 512 exists in several instantiations of the same radix-2 DIT graph: the lane-resident kernel (first six
+    stages in registers) compiled by hipRTC for exactly the FFT nodes the plan's bins need, the same kernel prebuilt for the
+    full graph, and the radix-8 exchange kernels (pruned or full graph, u8 through the level table or arithmetically).  Any
+    subset of the graph is computed with the same operations on the same operands, so audio, flags and raw I/Q are bit-exact
+    with the oracle for every one of them -- on the 8-channel AM plan and on the 32-channel mixed plan, calls of 6 and of
+    1 + 5 batches (a tail tile of 4 windows, a first call with AGC_EXTRA more windows)."""
+    opts, kind = STAGE1_VARIANTS[variant]
+    for name in ("config2", "config3"):
+        centre, chans = getattr(pkg, name + "_channels")()
+        if name == "config3":
+            for c in (1, 6, 17):
+                chans[c].has_iq_outputs = 1
+        dev = pkg.device_cfg(centerfreq=centre, fft_size_log=9)
+        nbat = 6
+        kw = {} if name == "config2" else dict(amp_q8=1024, active=lambda k: k % 4 != 2)
+        iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=2, **kw)
+        nb, owo, oaxc, oiq = oracle_run(dev, chans, iq, nbat, want_iq=True)
+        assert nb == nbat
+        for calls in ([6], [1, 5]):
+            d = pkg.Demod(dev, chans, max_batches=max(calls))
+            for k, v in opts.items():
+                d.set_option(getattr(pkg, k), v)
+            outs, flags, iqs, done = [], [], [], 0
+            for k in calls:
+                pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+                wo, axc, iqo, _ = d.process([iq[pos:]], k, want_iq=True)
+                outs.append(wo[:, :, :k * WAVE_BATCH]), flags.append(axc), iqs.append(iqo)
+                done += k
+            assert d.last_stage1() == kind, f"{variant}: the handle ran stage-1 kernel kind {d.last_stage1()}"
+            d.close()
+            wo, axc, iqo = np.concatenate(outs, axis=2), np.concatenate(flags, axis=2), np.concatenate(iqs, axis=2)
+            assert_same(axc[0], oaxc, f"{variant}, {name}, calls {calls}: flags")
+            assert_same(wo[0], owo, f"{variant}, {name}, calls {calls}: audio")
+            for c, ch in enumerate(chans):
+                if ch.has_iq_outputs:
+                    assert_same(iqo[0, c].reshape(-1), oiq[c], f"{variant}, {name}, calls {calls}: raw I/Q ch{c}")
+
+
+@pytest.mark.parametrize("sfmt", ["s8", "s16", "f32"])
+@pytest.mark.parametrize("misalign", [0, 1])
+def test_lane_resident_stage1_formats_and_odd_alignment(pkg, sfmt, misalign):
+    """The lane-resident kernel converts a tile's samples once into a float span, two samples per lane from one aligned load.
+    Other sample formats take the same path with wider loads, and a capture that starts on an odd sample (device pointer not
+    aligned to a pair of samples) goes through the unaligned conversion: both equal the exchange kernels bit for bit (which
+    the other tests pin to the oracle) on planes, audio and flags."""
+    import torch
+    centre, chans = pkg.config2_channels()
+    chans[2].has_iq_outputs = 1
+    chans[2].bandwidth = 8000
+    code = {"s8": pkg.SFMT_S8, "s16": pkg.SFMT_S16, "f32": pkg.SFMT_F32}[sfmt]
+    dev = pkg.device_cfg(centerfreq=centre, sfmt=code, fullscale={"s8": 127.5, "s16": 32767.0, "f32": 1.0}[sfmt])
+    nbat = 3
+    u8, _ = gen_iq(pkg, pkg.device_cfg(centerfreq=centre), centre, chans, nbat, gate_div=8)
+    x = u8.astype(np.float32) - 127.5
+    raw = {"s8": lambda: np.round(x - 0.5).astype(np.int8), "s16": lambda: np.round(x * 200.0).astype(np.int16),
+           "f32": lambda: (x / 128.0).astype(np.float32)}[sfmt]()
+    bps2 = 2 * raw.itemsize
+    pad = np.zeros(2 * misalign, raw.dtype)  # one complex sample in front: the capture then starts on an odd sample
+    buf = np.concatenate([pad, raw, np.zeros(64, raw.dtype)]).view(np.uint8)
+    d_buf = torch.from_numpy(buf).cuda()
+    base = d_buf.data_ptr() + misalign * bps2
+    assert base % bps2 == 0 and (base % (2 * bps2) != 0) == bool(misalign)
+    res = {}
+    for lane_fft in (1, 0):
+        d = pkg.Demod(dev, chans, max_batches=nbat)
+        d.set_option(pkg.OPT_LANE_FFT, lane_fft)
+        d_wo = torch.zeros((1, len(chans), nbat * WAVE_BATCH), dtype=torch.float32, device="cuda")
+        d_ax = torch.zeros((1, len(chans), nbat), dtype=torch.uint8, device="cuda")
+        d_zo = torch.zeros((1, len(chans), nbat * WAVE_BATCH, 2), dtype=torch.float32, device="cuda")
+        d.process_device(base, 0, nbat, d_wo.data_ptr(), d_ax.data_ptr(), d_iq_out_ptr=d_zo.data_ptr(), hip_stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert d.last_stage1() == (3 if lane_fft else 1)
+        planes = [d.read_planes(0, c, 0, nbat * WAVE_BATCH + AGC_EXTRA, want_iq=True) for c in range(len(chans))]
+        d.close()
+        res[lane_fft] = (d_wo.cpu().numpy(), d_ax.cpu().numpy(), d_zo.cpu().numpy(), planes)
+    assert (res[0][1] == ord("*")).any()
+    assert_same(res[1][0], res[0][0], "audio")
+    assert_same(res[1][1], res[0][1], "flags")
+    assert_same(res[1][2][0, 2], res[0][2][0, 2], "raw I/Q")
+    for c in range(len(chans)):
+        assert_same(res[1][3][c][0], res[0][3][c][0], f"magnitude plane ch{c}")
+    assert_same(res[1][3][2][1], res[0][3][2][1], "complex plane ch2")
 
 
 def _channel_zoo(pkg):

@@ -17,7 +17,7 @@ import sys
 
 
 def kernel(name):
-    m = re.search(r"(k_[a-z_0-9]+|__amd_rocclr_[A-Za-z]+)", name)
+    m = re.search(r"(k_[a-z_0-9]+|l64_entry|__amd_rocclr_[A-Za-z]+)", name)
     return m.group(1) if m else name
 
 

@@ -14,7 +14,7 @@ import sys
 
 
 def kernel(name):
-    m = re.search(r"(k_[a-z_0-9]+|__amd_rocclr_[A-Za-z]+)", name)
+    m = re.search(r"(k_[a-z_0-9]+|l64_entry|__amd_rocclr_[A-Za-z]+)", name)
     return m.group(1) if m else name
 
 
@@ -28,7 +28,7 @@ def main():
     mean = {k: sum(v) / len(v) for k, v in acc.items()}
     rows = []
     for (k, c), m in sorted(mean.items()):
-        if not k.startswith("k_"):
+        if not (k.startswith("k_") or k.startswith("l64")):
             continue
         share = ""
         wc = mean.get((k, "SQ_WAVE_CYCLES"))
