@@ -218,7 +218,7 @@ int build_plan(const mi_device_cfg& dev, const mi_channel_cfg* chans, int nch, P
         c.alpha = k.tau >= 0 ? alpha_for_tau(k.tau) : dev_alpha;
         c.one_minus_alpha = 1.0f - c.alpha;
         c.has_iq_outputs = k.has_iq_outputs ? 1 : 0;
-        c.needs_raw_iq = (k.has_iq_outputs || k.bandwidth > 0 || k.modulation == MI_MOD_NFM) ? 1 : 0;  // config.cpp:162,596,676
+        c.needs_raw_iq = (k.has_iq_outputs || k.bandwidth != 0 || k.modulation == MI_MOD_NFM) ? 1 : 0;  // config.cpp:162,596,676 (< 0: key present without a usable value)
 
         // Squelch(): default snr 9.54 dB; then squelch_threshold, then squelch_snr_threshold (config.cpp:440-518)
         float ratio = static_cast<float>(std::pow(10.0, 9.54f / 20.0));  // squelch.cpp:38,100 (db is a float)

@@ -47,29 +47,65 @@ void input_free(input_t* in) {
     free(in);
 }
 
-// input-helpers.cpp:37-63
+namespace {
+
+struct RingGuard {  // buffer_lock for the length of a scope
+    explicit RingGuard(input_t* in) : m(&in->buffer_lock) { pthread_mutex_lock(m); }
+    ~RingGuard() { pthread_mutex_unlock(m); }
+    pthread_mutex_t* m;
+};
+
+size_t tail_mirror_len(const input_t* in) {  // bytes kept behind buf_size as a copy of the ring's first bytes
+    return 2 * static_cast<size_t>(in->bytes_per_sample) * fft_size;
+}
+
+}  // namespace
+
+// The RX side of the ring.  Behaviour follows input-helpers.cpp:37-63 (the spec; tests/test_host_mirror.py compares every
+// byte and counter with a model of that rule): the bytes go in at the write position, in two pieces when they run past
+// buf_size; whatever piece landed at offset 0 is then copied, up to the mirror's length, behind buf_size, so that a window
+// starting near the end of the ring reads on without wrapping; the write position advances modulo buf_size; passing the
+// read position counts one overflow.
 void circbuffer_append(input_t* const input, unsigned char* buf, size_t len) {
-    if (len == 0)
+    if (!len)
         return;
-    pthread_mutex_lock(&input->buffer_lock);
-    size_t space_left = input->buf_size - input->bufe;
-    const size_t pad = 2 * input->bytes_per_sample * fft_size;
-    if (space_left >= len) {
-        memcpy(input->buffer + input->bufe, buf, len);
-        if (input->bufe == 0)
-            memcpy(input->buffer + input->buf_size, input->buffer, std::min(len, pad));
-    } else {
-        memcpy(input->buffer + input->bufe, buf, space_left);
-        memcpy(input->buffer, buf + space_left, len - space_left);
-        memcpy(input->buffer + input->buf_size, input->buffer, std::min(len - space_left, pad));
+    RingGuard hold(input);
+    const size_t start = input->bufe;
+    const size_t until_end = input->buf_size - start;
+    const size_t first = len <= until_end ? len : until_end;  // piece that fits before buf_size
+    const size_t second = len - first;                        // piece that continues at offset 0
+    memcpy(input->buffer + start, buf, first);
+    size_t at_front = 0;  // how many freshly written bytes begin at offset 0
+    if (second) {
+        memcpy(input->buffer, buf + first, second);
+        at_front = second;
+    } else if (start == 0) {
+        at_front = first;
     }
-    size_t old_end = input->bufe;
-    input->bufe = (input->bufe + len) % input->buf_size;
-    if (old_end < input->bufs && input->bufe >= input->bufs) {
+    if (at_front)
+        memcpy(input->buffer + input->buf_size, input->buffer, std::min(at_front, tail_mirror_len(input)));
+    input->bufe = (start + len) % input->buf_size;
+    if (start < input->bufs && input->bufe >= input->bufs) {
         fprintf(stderr, "Warning: buffer overflow\n");
         input->overflow_count++;
     }
-    pthread_mutex_unlock(&input->buffer_lock);
+}
+
+size_t ring_fill(input_t* in) {
+    RingGuard hold(in);
+    return in->bufe >= in->bufs ? in->bufe - in->bufs : in->buf_size - in->bufs + in->bufe;
+}
+
+const unsigned char* ring_contiguous(const input_t* in, size_t need, std::vector<unsigned char>& scratch) {
+    // (The mirrored tail is not relied on here: the reference's rule leaves part of it stale when a short append follows a
+    // wrap, and a batch is far longer than the tail anyway.)
+    if (in->bufs + need <= in->buf_size)
+        return in->buffer + in->bufs;
+    const size_t before_wrap = in->buf_size - in->bufs;
+    scratch.resize(need);
+    memcpy(scratch.data(), in->buffer + in->bufs, before_wrap);
+    memcpy(scratch.data() + before_wrap, in->buffer, need - before_wrap);
+    return scratch.data();
 }
 
 device_t* device_new(input_t* in, const mi_channel_cfg* chans, int nch, int tau) {
@@ -101,6 +137,14 @@ device_t* device_new(input_t* in, const mi_channel_cfg* chans, int nch, int tau)
     return dev;
 }
 
+std::vector<mi_channel_cfg> channel_cfgs_of(const device_t* dev) {
+    std::vector<mi_channel_cfg> out;
+    out.reserve((size_t)dev->channel_count);
+    for (int i = 0; i < dev->channel_count; i++)
+        out.push_back(dev->channels[i].cfg);
+    return out;
+}
+
 void device_free(device_t* dev) {
     if (!dev)
         return;
@@ -126,9 +170,7 @@ int init_demod(demod_params_t* params, Signal* signal, int device_start, int dev
         dc.fullscale = dev->input->fullscale;
         dc.tau = dev->tau;
         dc.fm_quadri = fm_quadri_demod_selected;
-        std::vector<mi_channel_cfg> cc((size_t)dev->channel_count);
-        for (int i = 0; i < dev->channel_count; i++)
-            cc[(size_t)i] = dev->channels[i].cfg;
+        std::vector<mi_channel_cfg> cc = channel_cfgs_of(dev);
         int rc = mi_demod_create(&dc, cc.data(), dev->channel_count, 1, 1, gpu, &dev->engine);
         if (rc != MI_OK) {
             fprintf(stderr, "init_demod: device %d: %s\n", d, mi_last_error());
@@ -138,101 +180,105 @@ int init_demod(demod_params_t* params, Signal* signal, int device_start, int dev
     return 0;
 }
 
-static int next_device(demod_params_t* params, int current) {  // rtl_airband.cpp:300-306
-    current++;
-    if (current < params->device_end)
-        return current;
-    return params->device_start;
-}
+namespace {
 
-void* demodulate(void* params) {
-    demod_params_t* demod_params = (demod_params_t*)params;
-    std::vector<unsigned char> linear;  // a batch that wraps the ring is linearised here
-    std::vector<float> wout, iqout;
+// The devices one demod thread serves, visited in turn (the reference walks [device_start, device_end) the same way,
+// rtl_airband.cpp:300-306).
+class DeviceTurn {
+   public:
+    DeviceTurn(int first, int end) : first_(first), end_(end), at_(first) {}
+    int current() const { return at_; }
+    void next() { at_ = (at_ + 1 < end_) ? at_ + 1 : first_; }
+
+   private:
+    int first_, end_, at_;
+};
+
+// Scratch of one demod thread: what one engine call returns before it is published into channel_t.
+struct BatchScratch {
+    std::vector<unsigned char> linear;
+    std::vector<float> wave, iq;
     std::vector<char> axc;
     std::vector<mi_channel_stats> stats;
-    size_t available;
-    int device_num = demod_params->device_start;
-    while (true) {
-        if (do_exit)
-            return NULL;
-        device_t* dev = devices + device_num;
-        input_t* in = dev->input;
+    void fit(int nch) {
+        wave.resize((size_t)nch * (WAVE_BATCH + AGC_EXTRA));
+        iq.resize((size_t)nch * WAVE_BATCH * 2);
+        axc.resize((size_t)nch);
+        stats.resize((size_t)nch);
+    }
+};
 
-        pthread_mutex_lock(&in->buffer_lock);
-        if (in->bufe >= in->bufs)
-            available = in->bufe - in->bufs;
-        else
-            available = in->buf_size - in->bufs + in->bufe;
-        pthread_mutex_unlock(&in->buffer_lock);
+// channel_t / freq_t after a batch, exactly what the reference's loop leaves: waveout[0, WAVE_BATCH) final and
+// [WAVE_BATCH, +AGC_EXTRA) lookahead, iq_out, axcindicate, the squelch statistics and counters (rtl_airband.cpp:612-669).
+void publish_batch(device_t* dev, const BatchScratch& b) {
+    for (int i = 0; i < dev->channel_count; i++) {
+        channel_t* ch = dev->channels + i;
+        freq_t* f = ch->freqlist + ch->freq_idx;
+        const size_t k = (size_t)i;
+        memcpy(ch->waveout, b.wave.data() + k * (WAVE_BATCH + AGC_EXTRA), (WAVE_BATCH + AGC_EXTRA) * sizeof(float));
+        if (ch->has_iq_outputs)
+            memcpy(ch->iq_out, b.iq.data() + k * WAVE_BATCH * 2, WAVE_BATCH * 2 * sizeof(float));
+        ch->axcindicate = (status)b.axc[k];
+        f->squelch = b.stats[k];
+        f->agcavgfast = b.stats[k].agcavgfast;
+        f->active_counter = (size_t)b.stats[k].active_counter;
+    }
+    __sync_synchronize();  // the output thread reads these without a lock once it sees waveavail (output.cpp:933-950)
+    if (dev->waveavail == 1)
+        dev->output_overrun_count++;  // the previous batch was not collected (rtl_airband.cpp:671-676)
+    else
+        dev->waveavail = 1;
+}
 
-        if (devices_running == 0) {  // rtl_airband.cpp:399-403
+}  // namespace
+
+// The demod thread.  Control flow of the reference's loop (rtl_airband.cpp:381-422, 671-691) with one engine call per
+// WAVE_BATCH in place of the per-window body: exit flag, "all receivers failed", skipping inputs that are not running
+// (a failed one is retired once), the availability rule, the 10 ms nap when the ring is short, publish, signal, advance.
+void* demodulate(void* params) {
+    demod_params_t* const dp = (demod_params_t*)params;
+    DeviceTurn turn(dp->device_start, dp->device_end);
+    BatchScratch scratch;
+    for (; !do_exit; ) {
+        device_t* const dev = devices + turn.current();
+        input_t* const in = dev->input;
+        const size_t fill = ring_fill(in);
+        if (devices_running == 0) {
             fprintf(stderr, "All receivers failed, exiting\n");
             do_exit = 1;
-            continue;
+            break;
         }
-        if (in->state != INPUT_RUNNING) {  // rtl_airband.cpp:405-413
-            if (in->state == INPUT_FAILED) {
+        if (in->state != INPUT_RUNNING) {
+            if (in->state == INPUT_FAILED) {  // retire it: its outputs stay silent from now on
                 in->state = INPUT_DISABLED;
                 devices_running--;
             }
-            device_num = next_device(demod_params, device_num);
+            turn.next();
             continue;
         }
-
-        // The reference runs one window per loop turn and a batch completes after WAVE_BATCH of them; here a whole
-        // batch is one engine call.  The availability rule of rtl_airband.cpp:417 applied to the batch's LAST window:
-        // consumed bytes + one window (= what the batch reads) + one hop.
+        // The reference starts a window when the ring holds one hop plus one window (rtl_airband.cpp:417).  Applied to the
+        // LAST window of a batch: everything the batch consumes, plus one window.
         const size_t consumed = mi_demod_bytes_consumed(dev->engine, 1);
-        const size_t needed = mi_demod_bytes_needed(dev->engine, 1);
-        if (available < consumed + fft_size * in->bytes_per_sample * 2) {
-            device_num = next_device(demod_params, device_num);
+        if (fill < consumed + fft_size * (size_t)in->bytes_per_sample * 2) {
+            turn.next();
             SLEEP(10);
             continue;
         }
-        const unsigned char* src = in->buffer + in->bufs;
-        if (in->bufs + needed > in->buf_size + 2 * in->bytes_per_sample * fft_size) {  // beyond the tail pad: wraps
-            linear.resize(needed);
-            const size_t first = in->buf_size - in->bufs;
-            memcpy(linear.data(), in->buffer + in->bufs, first);
-            memcpy(linear.data() + first, in->buffer, needed - first);
-            src = linear.data();
-        }
-        const int nch = dev->channel_count;
-        wout.resize((size_t)nch * (WAVE_BATCH + AGC_EXTRA));
-        iqout.resize((size_t)nch * WAVE_BATCH * 2);
-        axc.resize((size_t)nch);
-        stats.resize((size_t)nch);
+        const unsigned char* src = ring_contiguous(in, mi_demod_bytes_needed(dev->engine, 1), scratch.linear);
+        scratch.fit(dev->channel_count);
         const uint8_t* streams[1] = {src};
-        int rc = mi_demod_process(dev->engine, streams, 1, wout.data(), iqout.data(), axc.data(), stats.data());
-        if (rc != MI_OK) {  // a runtime engine failure is an input failure for that device
-            fprintf(stderr, "demodulate: device %d: %s\n", device_num, mi_last_error());
+        const int rc = mi_demod_process(dev->engine, streams, 1, scratch.wave.data(), scratch.iq.data(), scratch.axc.data(), scratch.stats.data());
+        if (rc != MI_OK) {  // an engine failure at run time is an input failure of that device
+            fprintf(stderr, "demodulate: device %d: %s\n", turn.current(), mi_last_error());
             in->state = INPUT_FAILED;
             continue;
         }
-        for (int i = 0; i < nch; i++) {
-            channel_t* channel = dev->channels + i;
-            freq_t* fparms = channel->freqlist + channel->freq_idx;
-            // channel_t.waveout as the reference's loop leaves it: [0, WAVE_BATCH) final, [WAVE_BATCH, +AGC_EXTRA) lookahead.
-            // Written before waveavail is published (the output thread reads it without a lock, output.cpp:933-950).
-            memcpy(channel->waveout, wout.data() + (size_t)i * (WAVE_BATCH + AGC_EXTRA), (WAVE_BATCH + AGC_EXTRA) * sizeof(float));
-            if (channel->has_iq_outputs)
-                memcpy(channel->iq_out, iqout.data() + (size_t)i * WAVE_BATCH * 2, WAVE_BATCH * 2 * sizeof(float));
-            channel->axcindicate = (status)axc[(size_t)i];
-            fparms->squelch = stats[(size_t)i];
-            fparms->agcavgfast = stats[(size_t)i].agcavgfast;
-            fparms->active_counter = (size_t)stats[(size_t)i].active_counter;  // rtl_airband.cpp:667-669
-        }
-        __sync_synchronize();
-        if (dev->waveavail == 1) {  // rtl_airband.cpp:671-676
-            dev->output_overrun_count++;
-        } else {
-            dev->waveavail = 1;
-        }
-        demod_params->mp3_signal->send();  // rtl_airband.cpp:684
+        publish_batch(dev, scratch);
+        dp->mp3_signal->send();                           // rtl_airband.cpp:684
         in->bufs = (in->bufs + consumed) % in->buf_size;  // rtl_airband.cpp:691
-        device_num = next_device(demod_params, device_num);
+        turn.next();
     }
+    return NULL;
 }
 
 int output_consume(device_t* dev, int device_index, output_sink_t sink, void* user) {

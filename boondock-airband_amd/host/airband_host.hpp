@@ -12,8 +12,10 @@
 #pragma once
 #include <pthread.h>
 
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 #include "../../include/mi_airband.h"
@@ -42,26 +44,23 @@ struct input_t {
     pthread_mutex_t buffer_lock;
 };
 
-class Signal {  // boondock_airband.h:210-230
+// The wake-up the demod thread gives the output threads once per batch (reference: class Signal, boondock_airband.h:210-230).
+// Same contract -- send() wakes one waiter, wait() blocks until the next send(), a send() nobody waits for is lost --
+// written over the C++11 primitives.
+class Signal {
    public:
-    Signal() {
-        pthread_cond_init(&cond_, NULL);
-        pthread_mutex_init(&mutex_, NULL);
-    }
     void send() {
-        pthread_mutex_lock(&mutex_);
-        pthread_cond_signal(&cond_);
-        pthread_mutex_unlock(&mutex_);
+        std::lock_guard<std::mutex> hold(m_);
+        cv_.notify_one();
     }
     void wait() {
-        pthread_mutex_lock(&mutex_);
-        pthread_cond_wait(&cond_, &mutex_);
-        pthread_mutex_unlock(&mutex_);
+        std::unique_lock<std::mutex> hold(m_);
+        cv_.wait(hold);
     }
 
    private:
-    pthread_cond_t cond_;
-    pthread_mutex_t mutex_;
+    std::mutex m_;
+    std::condition_variable cv_;
 };
 
 struct freq_t {
@@ -111,8 +110,18 @@ extern int devices_running;
 input_t* input_new_for_format(sample_format_t sfmt, int sample_rate, int centerfreq);  // ring sizing: config.cpp:799-805
 void input_free(input_t* in);
 void circbuffer_append(input_t* const input, unsigned char* buf, size_t len);
+// Bytes between the read and the write position of the ring (taken under buffer_lock, rtl_airband.cpp:392-397).
+size_t ring_fill(input_t* in);
+// `need` readable bytes starting at the read position as one contiguous run: a pointer into the ring when the run ends
+// before buf_size, else the run is assembled in `scratch`.  The reference never needs this -- it consumes one window per
+// turn, and a window always fits the mirrored tail behind buf_size -- a whole WAVE_BATCH per call does.
+// contiguous_or_linearised().
+const unsigned char* ring_contiguous(const input_t* in, size_t need, std::vector<unsigned char>& scratch);
 
 device_t* device_new(input_t* in, const mi_channel_cfg* chans, int nch, int tau);  // channel defaults: config.cpp:271-287,319-334
+// The DSP keys of a device's channels as the engine wants them (channel_cfgs_of(); in the reference tree the
+// values come from the members the config.cpp patch there adds to channel_t / freq_t).
+std::vector<mi_channel_cfg> channel_cfgs_of(const device_t* dev);
 void device_free(device_t* dev);
 
 // init_demod() (rtl_airband.cpp:253-266): creates the engine of every device in [device_start, device_end).

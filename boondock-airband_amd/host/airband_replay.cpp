@@ -45,7 +45,52 @@ static void sink_fn(void* user, int /*device*/, int channel, const float* waveou
     }
 }
 
+// --ring-selftest <buf_size> <fft_size> <bytes_per_sample> <op>...   (no GPU needed)
+//   a<len>  append len bytes (a running counter pattern)      c<n>  the consumer advances n bytes
+//   r<need> print the `need` bytes ring_contiguous() hands to the engine, as hex
+// After every op one line "bufs bufe overflow_count"; at the end the ring and its mirrored tail as hex.
+static int ring_selftest(int argc, char** argv) {
+    if (argc < 5)
+        return 2;
+    input_t in;
+    memset(&in, 0, sizeof(in));
+    in.buf_size = (size_t)atol(argv[2]);
+    fft_size = (size_t)atol(argv[3]);
+    in.bytes_per_sample = atoi(argv[4]);
+    const size_t tail = 2 * (size_t)in.bytes_per_sample * fft_size;
+    std::vector<unsigned char> store(in.buf_size + tail, 0xEE);
+    in.buffer = store.data();
+    pthread_mutex_init(&in.buffer_lock, NULL);
+    unsigned counter = 0;
+    std::vector<unsigned char> scratch, chunk;
+    for (int i = 5; i < argc; i++) {
+        const char op = argv[i][0];
+        const size_t n = (size_t)atol(argv[i] + 1);
+        if (op == 'a') {
+            chunk.resize(n);
+            for (size_t k = 0; k < n; k++)
+                chunk[k] = (unsigned char)(counter++ * 7u + 1u);
+            circbuffer_append(&in, chunk.data(), n);
+        } else if (op == 'c') {
+            in.bufs = (in.bufs + n) % in.buf_size;
+        } else if (op == 'r') {
+            const unsigned char* p = ring_contiguous(&in, n, scratch);
+            printf("r ");
+            for (size_t k = 0; k < n; k++)
+                printf("%02x", p[k]);
+            printf("\n");
+        }
+        printf("%zu %zu %zu %zu\n", in.bufs, in.bufe, in.overflow_count, ring_fill(&in));
+    }
+    for (unsigned char b : store)
+        printf("%02x", b);
+    printf("\n");
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && strcmp(argv[1], "--ring-selftest") == 0)
+        return ring_selftest(argc, argv);
     if (argc < 4) {
         fprintf(stderr, "usage: %s <config.txt> <capture.iq> <out_prefix> [gpu]\n", argv[0]);
         return 2;

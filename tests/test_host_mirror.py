@@ -79,3 +79,82 @@ def test_replay_through_ring_equals_oracle(pkg, tmp_path, case):
             want = np.concatenate([oiq[c, 2 * b * WAVE_BATCH:2 * (b + 1) * WAVE_BATCH] for b in keep] or [np.zeros(0, np.float32)])
             assert_same(raw, want, f"{case} ch{c} rawfile cf32 stream")
             assert raw.size > 0
+
+
+# ---- the ring: input-helpers.cpp:37-63 is the spec ----
+
+class RingModel:
+    """The reference's circbuffer_append rule restated (input-helpers.cpp:37-63): two-piece copy at the wrap, the piece that
+    lands at offset 0 mirrored (up to 2 * bytes_per_sample * fft_size bytes) behind buf_size, write position modulo buf_size,
+    one overflow when the write position passes the read position; availability as rtl_airband.cpp:392-397."""
+
+    def __init__(self, buf_size, fft_size, bps):
+        self.n, self.tail = buf_size, 2 * bps * fft_size
+        self.buf = bytearray([0xEE]) * (buf_size + self.tail)
+        self.bufs = self.bufe = self.overflow = 0
+        self.counter = 0
+
+    def append(self, length):
+        data = bytes(((self.counter + k) * 7 + 1) & 0xff for k in range(length))
+        self.counter += length
+        if length == 0:
+            return
+        space_left = self.n - self.bufe
+        if space_left >= length:
+            self.buf[self.bufe:self.bufe + length] = data
+            if self.bufe == 0:
+                m = min(length, self.tail)
+                self.buf[self.n:self.n + m] = self.buf[0:m]
+        else:
+            self.buf[self.bufe:self.n] = data[:space_left]
+            self.buf[0:length - space_left] = data[space_left:]
+            m = min(length - space_left, self.tail)
+            self.buf[self.n:self.n + m] = self.buf[0:m]
+        old_end = self.bufe
+        self.bufe = (self.bufe + length) % self.n
+        if old_end < self.bufs and self.bufe >= self.bufs:
+            self.overflow += 1
+
+    def consume(self, n):
+        self.bufs = (self.bufs + n) % self.n
+
+    def fill(self):
+        return self.bufe - self.bufs if self.bufe >= self.bufs else self.n - self.bufs + self.bufe
+
+    def read(self, need):
+        """What a consumer reading `need` bytes from the read position must see (the ring is circular)."""
+        return bytes(self.buf[(self.bufs + k) % self.n] for k in range(need))
+
+
+@pytest.mark.parametrize("ops", [
+    # fill exactly to the end, start again at offset 0 (mirror refreshed), wrap in the middle of an append
+    ["a1000", "a24", "a100", "c900", "a700", "a400", "r200"],
+    # appends shorter and longer than the mirrored tail at the wrap; a read that ends inside the tail and one beyond it
+    ["a1020", "c1000", "a10", "r30", "a200", "c30", "r190", "a900", "r64", "c1000", "a77", "r100"],
+    # the writer laps the reader: overflow counted once per pass
+    ["a600", "c100", "a600", "a600", "c50", "a1024", "a1"],
+    # an append starting inside the mirrored region without a wrap leaves the tail as it was (the reference's rule)
+    ["a1024", "c1024", "a5", "a20", "c20", "a1019", "r40"],
+])
+def test_ring_behaves_like_the_reference_rule(ops):
+    """The host mirror's circbuffer_append / availability / linearisation against a model of input-helpers.cpp:37-63, byte
+    for byte including the mirrored tail, on a 1024-byte ring with a 32-byte tail (fft 16, u8): every wrap and tail-pad edge."""
+    exe = os.path.join(ROOT, "boondock-airband_amd", "host", "airband_replay")
+    if not os.path.exists(exe):
+        pytest.skip("airband_replay not built")
+    r = subprocess.run([exe, "--ring-selftest", "1024", "16", "1"] + ops, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().split("\n")
+    m = RingModel(1024, 16, 1)
+    it = iter(lines)
+    for op in ops:
+        n = int(op[1:])
+        if op[0] == "a":
+            m.append(n)
+        elif op[0] == "c":
+            m.consume(n)
+        else:
+            got = next(it)
+            assert got == "r " + m.read(n).hex(), f"{op}: bytes handed to the engine differ from the circular read"
+        assert next(it) == f"{m.bufs} {m.bufe} {m.overflow} {m.fill()}", f"after {op}"
+    assert next(it) == bytes(m.buf).hex(), "ring + mirrored tail"
