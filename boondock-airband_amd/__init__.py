@@ -93,7 +93,7 @@ class MixInput(C.Structure):  # mi_mix_input
 
 ABI_SYMBOLS = [
     "mi_last_error", "mi_device_count", "mi_demod_create", "mi_demod_destroy", "mi_demod_bytes_needed", "mi_demod_bytes_consumed",
-    "mi_demod_hop_bytes", "mi_demod_process", "mi_demod_process_device", "mi_demod_get_stats", "mi_demod_state_size",
+    "mi_demod_hop_bytes", "mi_demod_process", "mi_demod_submit", "mi_demod_wait", "mi_host_alloc", "mi_host_free", "mi_demod_process_device", "mi_demod_get_stats", "mi_demod_state_size",
     "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_last_stage1", "mi_demod_tp_debug", "mi_demod_kernel_time", "mi_demod_kernel_time_prev", "mi_demod_set_option", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
     "mi_plan_window", "mi_plan_twiddles", "mi_plan_levels", "mi_plan_sincos_lut", "mi_plan_channel", "mi_plan_ctcss_coeffs",
     "mi_iqgen_host", "mi_iqgen_device", "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_is_stereo", "mi_mixer_process_device",
@@ -115,6 +115,12 @@ def lib():
         L.mi_demod_create.argtypes = [C.POINTER(DeviceCfg), C.POINTER(ChannelCfg), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.mi_demod_destroy.argtypes = [vp]
         L.mi_demod_last_stage1.argtypes = [vp, C.POINTER(C.c_int)]
+        L.mi_demod_submit.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
+        L.mi_demod_wait.argtypes = [vp]
+        L.mi_host_alloc.argtypes = [sz]
+        L.mi_host_alloc.restype = vp
+        L.mi_host_free.argtypes = [vp]
+        L.mi_host_free.restype = None
         L.mi_demod_destroy.restype = None
         for f in (L.mi_demod_bytes_needed, L.mi_demod_bytes_consumed):
             f.argtypes = [vp, C.c_int]
@@ -270,6 +276,40 @@ class Demod:
                                       None if stats is None else C.cast(stats, C.c_void_p)))
         return wo, axc, iqo, stats
 
+    def submit(self, iq_streams, nbatches, want_iq=False, want_stats=True, waveout=None):
+        """mi_demod_submit: starts a call and returns a ticket; wait() completes the oldest ticket and returns its results
+        like process().  The numpy arrays of a ticket stay referenced until it has been waited for."""
+        assert len(iq_streams) == self.nstreams
+        need = self.bytes_needed(nbatches)
+        keep = [a if isinstance(a, PinnedBuffer) else np.ascontiguousarray(a, dtype=np.uint8) for a in iq_streams]
+        addr = [a.ptr if isinstance(a, PinnedBuffer) else a.ctypes.data for a in keep]
+        ptrs = (C.c_void_p * self.nstreams)(*addr)
+        n = nbatches * WAVE_BATCH
+        # waveout: an optional caller-owned float32 array [nstreams][nch][n + AGC_EXTRA] (e.g. a view of a PinnedBuffer)
+        wo = waveout if waveout is not None else np.empty((self.nstreams, self.nch, n + AGC_EXTRA), np.float32)
+        assert wo.dtype == np.float32 and wo.size == self.nstreams * self.nch * (n + AGC_EXTRA) and wo.flags["C_CONTIGUOUS"]
+        axc = np.zeros((self.nstreams, self.nch, nbatches), np.uint8)
+        iqo = np.zeros((self.nstreams, self.nch, n, 2), np.float32) if want_iq else None
+        stats = (ChannelStats * (self.nstreams * self.nch))() if want_stats else None
+        _check(lib().mi_demod_submit(self._h, ptrs, nbatches, wo.ctypes.data_as(C.c_void_p),
+                                     None if iqo is None else iqo.ctypes.data_as(C.c_void_p), axc.ctypes.data_as(C.c_void_p),
+                                     None if stats is None else C.cast(stats, C.c_void_p)))
+        if not hasattr(self, "_tickets"):
+            self._tickets = []
+        self._tickets.append((keep, ptrs, wo, axc, iqo, stats))
+        while len(self._tickets) > 2:  # a third submit completed the oldest call inside the library
+            self._done = getattr(self, "_done", []) + [self._tickets.pop(0)]
+
+    def wait(self):
+        """Results (waveout, axc, iq_out, stats) of the oldest submitted call."""
+        done = getattr(self, "_done", [])
+        if done:
+            t = done.pop(0)
+            return t[2], t[3], t[4], t[5]
+        _check(lib().mi_demod_wait(self._h))
+        t = self._tickets.pop(0)
+        return t[2], t[3], t[4], t[5]
+
     def process_device(self, d_iq_ptr, stream_stride, nbatches, d_waveout_ptr, d_axc_ptr, d_iq_out_ptr=None, hip_stream=None):
         """Device-resident entry: raw device pointers (ints), asynchronous on hip_stream."""
         _check(lib().mi_demod_process_device(self._h, d_iq_ptr, stream_stride, nbatches, d_waveout_ptr, d_iq_out_ptr, d_axc_ptr, hip_stream))
@@ -371,6 +411,32 @@ def iqgen_host(cfg, stream_id, first, count):
 
 def iqgen_device(cfg, first_stream_id, nstreams, stream_stride, first, count, d_out_ptr, hip_stream=None):
     _check(lib().mi_iqgen_device(C.byref(cfg), first_stream_id, nstreams, stream_stride, first, count, d_out_ptr, hip_stream))
+
+
+class PinnedBuffer:
+    """Page-locked host memory from mi_host_alloc, viewed as a uint8 numpy array (.array); .ptr is its address."""
+
+    def __init__(self, nbytes, _root=None, _ptr=None):
+        self._root = _root
+        if _root is None:
+            self._mem = lib().mi_host_alloc(nbytes)
+            if not self._mem:
+                raise MemoryError("mi_host_alloc failed")
+            self.ptr = self._mem
+        else:
+            self._mem = None
+            self.ptr = _ptr
+        self.nbytes = nbytes
+        self.array = np.ctypeslib.as_array((C.c_ubyte * nbytes).from_address(self.ptr))
+
+    def view(self, offset):
+        """The same memory from `offset` on (a stream position inside a pinned capture)."""
+        return PinnedBuffer(self.nbytes - offset, self._root or self, self.ptr + offset)
+
+    def free(self):
+        if self._mem:
+            lib().mi_host_free(self._mem)
+            self._mem = None
 
 
 class Mixer:

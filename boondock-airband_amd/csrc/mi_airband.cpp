@@ -138,14 +138,31 @@ struct mi_demod {
     float* d_ctcss_coeff = nullptr;
     float* d_ctcss_q = nullptr;
     mi_channel_stats* d_stats = nullptr;
-    // staging for the host-buffer entry
-    unsigned char* d_iq = nullptr;
-    size_t iq_stride = 0;
-    float* d_wout = nullptr;
-    float2* d_iqout = nullptr;
-    char* d_axc = nullptr;
-    unsigned char* h_pin = nullptr;  // pinned bounce buffer for the IQ upload
-    size_t h_pin_bytes = 0;
+    // staging for the host-buffer entries: two slots, so that a second call can be uploaded while the first computes
+    // (mi_demod_submit / mi_demod_wait; mi_demod_process uses slot 0 alone)
+    struct Slot {
+        unsigned char* d_iq = nullptr;   // [nstreams][iq_stride]
+        float* d_wout = nullptr;         // [rows][max steps + AGC_EXTRA]: emitted audio + lookahead, the host layout
+        float2* d_iqout = nullptr;       // [rows][max steps]
+        char* d_axc = nullptr;           // [rows][max batches]
+        mi_channel_stats* d_stats = nullptr;  // [rows] snapshot of the statistics after this call
+        unsigned char* h_in = nullptr;   // pinned: upload staging for sources that are not pinned themselves
+        unsigned char* h_out = nullptr;  // pinned: audio / raw I/Q / flags / statistics on their way back
+        hipEvent_t up_done = nullptr, done = nullptr;
+        bool busy = false;
+        // where the results of the call in flight go
+        int nbatches = 0;
+        float* waveout = nullptr;
+        float* iq_out = nullptr;
+        char* axc = nullptr;
+        mi_channel_stats* stats = nullptr;
+        bool wave_direct = false;  // waveout is page-locked: the audio is downloaded straight into it
+    } slot[2];
+    size_t iq_stride = 0, h_out_bytes = 0;
+    bool slots_ready[2] = {false, false};
+    int slot_next = 0, slot_oldest = 0, in_flight = 0;
+    hipStream_t copy_stream = nullptr;  // uploads of submitted calls
+    hipStream_t down_stream = nullptr;  // their downloads
     // time-parallel stage 2 (tp.hip): only when every channel is a plain AM channel
     bool tp_eligible = false;
     int last_path = 0;  // 0 = serial kernel, 1 = time-parallel
@@ -245,7 +262,10 @@ bool serial_sets_ready(mi_demod* h) {
 }
 
 int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t valid_bytes, int nbatches, float* d_wmain, size_t wmain_stride,
-            float2* d_iq_out, size_t iq_out_stride, char* d_axc, hipStream_t s) {
+            float2* d_iq_out, size_t iq_out_stride, char* d_axc, hipStream_t s, hipEvent_t iq_ready = nullptr) {
+    // iq_ready (host-buffer entry, calls in flight): the IQ becomes valid when this event fires -- the streams that read it wait
+    // for it and for nothing else, exactly as if the caller had vouched for the bytes (MI_OPT_EARLY_INPUT)
+    const bool early_input = h->early_input || iq_ready != nullptr;
     const int nfft = n_fft_for(h, nbatches);
     mi::ChannelizeArgs ca{};
     ca.iq = d_iq;
@@ -349,7 +369,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         // and fix passes of the previous call: consecutive calls overlap and the core chain runs back to back.
         const int q = (h->cur + 1) % mi_demod::kSets;  // the scratch set of this call
         float* const planes = h->d_mag_set[q];
-        const bool overlap = h->early_input && h->chain_live && !h->first_call;
+        const bool overlap = early_input && h->chain_live && !h->first_call;
         const float* out_lo = d_wmain;
         const float* out_hi = d_wmain + static_cast<size_t>(h->rows - 1) * wmain_stride + da.nsteps;
         // segment passes may run under the previous call's tail only if they write a different audio buffer
@@ -473,6 +493,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         HIP_TRY(hipEventRecord(evc[1], s));
         HIP_TRY(mi::launch_tp_audio_head(ta, s));
         HIP_TRY(hipEventRecord(h->ev_head, s));  // the previous call is complete and its lookahead has been taken over
+        if (iq_ready)
+            HIP_TRY(hipStreamWaitEvent(fs, iq_ready, 0));
         if (!overlap)
             HIP_TRY(hipStreamWaitEvent(fs, h->ev_entry, 0));  // stage 1 honours the caller's stream order
         else if (h->set_seq[q])
@@ -542,6 +564,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         h->prev_out_lo = out_lo;
         h->prev_out_hi = out_hi;
     } else if (h->plan.any_afc) {
+        if (iq_ready)
+            HIP_TRY(hipStreamWaitEvent(s, iq_ready, 0));
         // AFC (rtl_airband.cpp:180-251): the bins stage 1 picks in batch b+1 depend on the squelch outcome of batch b, so
         // the batches are enqueued one at a time -- stage 1, channel loop, AFC::finalize -- with the bin table and the
         // previous indicator resident in ChanState: no host round trip inside the call.
@@ -579,7 +603,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             HIP_TRY(mi::launch_afc(aa, s));
             f0 += nf;
         }
-    } else if (h->early_input && !h->tp_eligible && !h->first_call && serial_sets_ready(h)) {
+    } else if (early_input && !h->tp_eligible && !h->first_call && serial_sets_ready(h)) {
         // ---- serial stage 2 with consecutive calls overlapping (MI_OPT_EARLY_INPUT) ----
         // Two plane sets alternate.  Stage 1 of this call fills the body of set p on the front stream while the previous
         // call's k_demod, which reads the other set, still runs on the caller's stream (all that k_demod writes into set p
@@ -590,6 +614,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         const int p = h->pset, np = p ^ 1;
         evc = h->ev[q];
         hipStream_t fs = h->front_stream;
+        if (iq_ready)
+            HIP_TRY(hipStreamWaitEvent(fs, iq_ready, 0));
         if (h->serial_pipe && h->set_seq[before_prev])  // the call before the previous one read the body of set p
             HIP_TRY(hipStreamWaitEvent(fs, h->ev[before_prev][2], 0));
         else
@@ -616,6 +642,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         h->serial_pipe = true;
         pipelined_serial = true;
     } else {
+        if (iq_ready)
+            HIP_TRY(hipStreamWaitEvent(s, iq_ready, 0));
         int rc = head_in_place();
         if (rc != MI_OK)
             return rc;
@@ -655,7 +683,7 @@ void mi_demod_destroy(mi_demod* h) {
     (void)hipSetDevice(h->gpu);
     (void)hipDeviceSynchronize();  // calls may still be in flight on the handle's own streams
     void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_t1, h->d_prune_t2, h->d_prune_rank, h->d_l64_chan, h->d_l64_chan_full, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx_set[0], h->d_cplx_set[1], h->d_carry,
-                    h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_iq, h->d_wout, h->d_iqout, h->d_axc,
+                    h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats,
                     h->d_rows,   h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_fullbound, h->d_afc_spec};
     for (void* p : ptrs)
         if (p)
@@ -666,8 +694,24 @@ void mi_demod_destroy(mi_demod* h) {
             if (p)
                 (void)hipFree(p);
     }
-    if (h->h_pin)
-        (void)hipHostFree(h->h_pin);
+    for (mi_demod::Slot& sl : h->slot) {
+        void* dev[] = {sl.d_iq, sl.d_wout, sl.d_iqout, sl.d_axc, sl.d_stats};
+        for (void* p : dev)
+            if (p)
+                (void)hipFree(p);
+        if (sl.h_in)
+            (void)hipHostFree(sl.h_in);
+        if (sl.h_out)
+            (void)hipHostFree(sl.h_out);
+        if (sl.up_done)
+            (void)hipEventDestroy(sl.up_done);
+        if (sl.done)
+            (void)hipEventDestroy(sl.done);
+    }
+    if (h->copy_stream)
+        (void)hipStreamDestroy(h->copy_stream);
+    if (h->down_stream)
+        (void)hipStreamDestroy(h->down_stream);
     for (int q = 0; q < mi_demod::kSets; ++q) {
         for (hipEvent_t e : h->ev[q])
             if (e)
@@ -886,56 +930,256 @@ int mi_demod_process_device(mi_demod* h, const void* d_iq, size_t stream_stride_
                    reinterpret_cast<float2*>(d_iq_out), nsteps, d_axc, static_cast<hipStream_t>(hip_stream));
 }
 
-int mi_demod_process(mi_demod* h, const uint8_t* const* iq, int nbatches, float* waveout, float* iq_out, char* axc, mi_channel_stats* stats) {
+namespace {
+
+// Staging of slot k, allocated on first use and only committed when every piece exists (a failure leaves the slot unallocated
+// and the handle usable: the next call tries again).
+int slot_prepare(mi_demod* h, int k) {
+    if (h->slots_ready[k])
+        return MI_OK;
+    mi_demod::Slot tmp;
+    const size_t rows = static_cast<size_t>(h->rows);
+    const size_t max_steps = static_cast<size_t>(h->max_batches) * mi::kWaveBatch;
+    const size_t max_fft = max_steps + mi::kAgcExtra;
+    const size_t stride = ((max_fft - 1) * h->plan.hop_bytes + 2 * static_cast<size_t>(h->plan.bytes_per_sample) * h->plan.fft_size + 255) & ~static_cast<size_t>(255);
+    const size_t out_bytes = rows * (max_steps + mi::kAgcExtra) * 4 + rows * max_steps * 8 + rows * static_cast<size_t>(h->max_batches) + rows * sizeof(mi_channel_stats) + 64;
+    hipError_t e = dalloc(&tmp.d_iq, stride * h->nstreams);
+    if (e == hipSuccess)
+        e = dalloc(&tmp.d_wout, rows * (max_steps + mi::kAgcExtra));
+    if (e == hipSuccess)
+        e = dalloc(&tmp.d_iqout, rows * max_steps);
+    if (e == hipSuccess)
+        e = dalloc(&tmp.d_axc, rows * static_cast<size_t>(h->max_batches));
+    if (e == hipSuccess)
+        e = dalloc(&tmp.d_stats, rows);
+    if (e == hipSuccess)
+        e = hipHostMalloc(reinterpret_cast<void**>(&tmp.h_in), stride * h->nstreams, hipHostMallocDefault);
+    if (e == hipSuccess)
+        e = hipHostMalloc(reinterpret_cast<void**>(&tmp.h_out), out_bytes, hipHostMallocDefault);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&tmp.up_done, hipEventDisableTiming);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&tmp.done, hipEventDisableTiming);
+    if (e == hipSuccess && !h->copy_stream)
+        e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess && !h->down_stream)
+        e = hipStreamCreateWithFlags(&h->down_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        void* dev[] = {tmp.d_iq, tmp.d_wout, tmp.d_iqout, tmp.d_axc, tmp.d_stats};
+        for (void* p : dev)
+            if (p)
+                (void)hipFree(p);
+        if (tmp.h_in)
+            (void)hipHostFree(tmp.h_in);
+        if (tmp.h_out)
+            (void)hipHostFree(tmp.h_out);
+        if (tmp.up_done)
+            (void)hipEventDestroy(tmp.up_done);
+        if (tmp.done)
+            (void)hipEventDestroy(tmp.done);
+        return hip_fail(e, "staging for the host-buffer entry");
+    }
+    h->iq_stride = stride;
+    h->h_out_bytes = out_bytes;
+    h->slot[k] = tmp;
+    h->slots_ready[k] = true;
+    return MI_OK;
+}
+
+// Is `p` host memory the GPU can read directly (hipHostMalloc / hipHostRegister / mi_host_alloc)?  Then the upload needs no
+// staging copy: the copy engine reads the caller's ring itself.
+bool is_pinned(const void* p) {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// offsets of the pieces of a call's results inside a slot's pinned return buffer
+struct OutLayout {
+    size_t wave, iq, axc, stats;
+};
+OutLayout out_layout(const mi_demod* h, int nbatches) {
+    const size_t rows = static_cast<size_t>(h->rows), n = static_cast<size_t>(nbatches) * mi::kWaveBatch;
+    OutLayout o;
+    o.wave = 0;
+    o.iq = o.wave + rows * (n + mi::kAgcExtra) * 4;
+    o.axc = o.iq + rows * n * 8;
+    o.stats = (o.axc + rows * static_cast<size_t>(nbatches) + 15) & ~static_cast<size_t>(15);
+    return o;
+}
+
+// upload + both stages + download of one call, all asynchronous; `pipelined`: upload and download on their own streams so
+// that they overlap the compute of the neighbouring calls
+int slot_launch(mi_demod* h, int k, const uint8_t* const* iq, int nbatches, bool want_iq, bool want_stats, bool pipelined) {
+    mi_demod::Slot& sl = h->slot[k];
+    const size_t rows = static_cast<size_t>(h->rows);
+    const size_t nsteps = static_cast<size_t>(nbatches) * mi::kWaveBatch;
+    const size_t need = mi_demod_bytes_needed(h, nbatches);
+    hipStream_t s = h->own_stream;
+    hipStream_t up = pipelined ? h->copy_stream : s;
+    for (int i = 0; i < h->nstreams; ++i) {
+        if (!iq[i])
+            return fail(MI_ERR_INVALID, "NULL stream pointer");
+        const unsigned char* src = iq[i];
+        if (!is_pinned(src)) {
+            std::memcpy(sl.h_in + static_cast<size_t>(i) * h->iq_stride, src, need);
+            src = sl.h_in + static_cast<size_t>(i) * h->iq_stride;
+        }
+        HIP_TRY(hipMemcpyAsync(sl.d_iq + static_cast<size_t>(i) * h->iq_stride, src, need, hipMemcpyHostToDevice, up));
+    }
+    hipEvent_t ready = nullptr;
+    if (pipelined) {
+        HIP_TRY(hipEventRecord(sl.up_done, up));
+        ready = sl.up_done;
+    }
+    // the staging copy is ordered by the stream / by `ready`: MI_OPT_EARLY_INPUT (valid when the call is made) does not hold here
+    const bool early = h->early_input;
+    h->early_input = false;
+    const size_t wstride = nsteps + mi::kAgcExtra;  // the host layout: emitted audio followed by the lookahead (channel_t.waveout)
+    int rc = enqueue(h, sl.d_iq, h->iq_stride, need, nbatches, sl.d_wout, wstride, want_iq ? sl.d_iqout : nullptr, nsteps, sl.d_axc, s, ready);
+    h->early_input = early;
+    if (rc != MI_OK)
+        return rc;
+    // the lookahead and the statistics belong to the handle and move on with the next call: snapshot them behind this one
+    HIP_TRY(hipMemcpy2DAsync(sl.d_wout + nsteps, wstride * sizeof(float), h->d_carry, mi::kAgcExtra * sizeof(float), mi::kAgcExtra * sizeof(float), rows,
+                             hipMemcpyDeviceToDevice, s));
+    if (want_stats)
+        HIP_TRY(hipMemcpyAsync(sl.d_stats, h->d_stats, rows * sizeof(mi_channel_stats), hipMemcpyDeviceToDevice, s));
+    hipStream_t down = s;
+    if (pipelined) {
+        HIP_TRY(hipEventRecord(sl.done, s));
+        HIP_TRY(hipStreamWaitEvent(h->down_stream, sl.done, 0));
+        down = h->down_stream;
+    }
+    const OutLayout o = out_layout(h, nbatches);
+    sl.wave_direct = is_pinned(sl.waveout);
+    HIP_TRY(hipMemcpyAsync(sl.wave_direct ? reinterpret_cast<unsigned char*>(sl.waveout) : sl.h_out + o.wave, sl.d_wout, rows * wstride * sizeof(float),
+                           hipMemcpyDeviceToHost, down));
+    if (want_iq) {
+        for (size_t r = 0; r < rows; ++r) {
+            if (!h->plan.cp[r % h->nch].has_iq_outputs)
+                continue;
+            HIP_TRY(hipMemcpyAsync(sl.h_out + o.iq + r * nsteps * 8, sl.d_iqout + r * nsteps, nsteps * sizeof(float2), hipMemcpyDeviceToHost, down));
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(sl.h_out + o.axc, sl.d_axc, rows * static_cast<size_t>(nbatches), hipMemcpyDeviceToHost, down));
+    if (want_stats)
+        HIP_TRY(hipMemcpyAsync(sl.h_out + o.stats, sl.d_stats, rows * sizeof(mi_channel_stats), hipMemcpyDeviceToHost, down));
+    HIP_TRY(hipEventRecord(sl.done, down));
+    return MI_OK;
+}
+
+// wait for slot k's call and hand its results to the caller's arrays
+int slot_collect(mi_demod* h, int k) {
+    mi_demod::Slot& sl = h->slot[k];
+    HIP_TRY(hipEventSynchronize(sl.done));
+    const size_t rows = static_cast<size_t>(h->rows);
+    const size_t nsteps = static_cast<size_t>(sl.nbatches) * mi::kWaveBatch;
+    const OutLayout o = out_layout(h, sl.nbatches);
+    if (!sl.wave_direct)
+        std::memcpy(sl.waveout, sl.h_out + o.wave, rows * (nsteps + mi::kAgcExtra) * sizeof(float));
+    if (sl.iq_out) {
+        for (size_t r = 0; r < rows; ++r)
+            if (h->plan.cp[r % h->nch].has_iq_outputs)  // rows of channels without iq outputs are untouched
+                std::memcpy(sl.iq_out + r * nsteps * 2, sl.h_out + o.iq + r * nsteps * 8, nsteps * 8);
+    }
+    std::memcpy(sl.axc, sl.h_out + o.axc, rows * static_cast<size_t>(sl.nbatches));
+    if (sl.stats)
+        std::memcpy(sl.stats, sl.h_out + o.stats, rows * sizeof(mi_channel_stats));
+    sl.busy = false;
+    return MI_OK;
+}
+
+int check_host_call(mi_demod* h, const uint8_t* const* iq, int nbatches, float* waveout, char* axc) {
     if (!h || !iq || !waveout || !axc)
         return fail(MI_ERR_INVALID, "NULL argument");
     if (nbatches < 1 || nbatches > h->max_batches)
         return fail(MI_ERR_INVALID, "nbatches out of range for this handle");
+    return MI_OK;
+}
+
+}  // namespace
+
+void* mi_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void mi_host_free(void* p) {
+    if (p)
+        (void)hipHostFree(p);
+}
+
+int mi_demod_wait(mi_demod* h) {
+    if (!h)
+        return fail(MI_ERR_INVALID, "NULL handle");
+    if (h->in_flight == 0)
+        return fail(MI_ERR_INVALID, "no submitted call is in flight");
     HIP_TRY(hipSetDevice(h->gpu));
-    const size_t rows = static_cast<size_t>(h->rows);
-    const size_t nsteps = static_cast<size_t>(nbatches) * mi::kWaveBatch;
-    if (!h->d_iq) {  // staging sized for the largest call, allocated on first use
-        const size_t max_fft = static_cast<size_t>(h->max_batches) * mi::kWaveBatch + mi::kAgcExtra;
-        h->iq_stride = ((max_fft - 1) * h->plan.hop_bytes + 2 * static_cast<size_t>(h->plan.bytes_per_sample) * h->plan.fft_size + 255) & ~static_cast<size_t>(255);
-        HIP_TRY(dalloc(&h->d_iq, h->iq_stride * h->nstreams));
-        HIP_TRY(dalloc(&h->d_wout, rows * static_cast<size_t>(h->max_batches) * mi::kWaveBatch));
-        HIP_TRY(dalloc(&h->d_iqout, rows * static_cast<size_t>(h->max_batches) * mi::kWaveBatch));
-        HIP_TRY(dalloc(&h->d_axc, rows * static_cast<size_t>(h->max_batches)));
-        h->h_pin_bytes = h->iq_stride * h->nstreams;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), h->h_pin_bytes, hipHostMallocDefault));
-    }
-    const size_t need = mi_demod_bytes_needed(h, nbatches);
-    hipStream_t s = h->own_stream;
-    for (int i = 0; i < h->nstreams; ++i) {
-        if (!iq[i])
-            return fail(MI_ERR_INVALID, "NULL stream pointer");
-        std::memcpy(h->h_pin + static_cast<size_t>(i) * h->iq_stride, iq[i], need);
-    }
-    HIP_TRY(hipMemcpyAsync(h->d_iq, h->h_pin, h->iq_stride * (h->nstreams - 1) + need, hipMemcpyHostToDevice, s));
-    // the staging copy above is in stream order: MI_OPT_EARLY_INPUT (the IQ is valid when the call is made) does not hold here
-    const bool early = h->early_input;
-    h->early_input = false;
-    int rc = enqueue(h, h->d_iq, h->iq_stride, need, nbatches, h->d_wout, nsteps, iq_out ? h->d_iqout : nullptr, nsteps, h->d_axc, s);
-    h->early_input = early;
+    const int k = h->slot_oldest;
+    int rc = slot_collect(h, k);
+    h->slot_oldest ^= 1;
+    h->in_flight--;
+    return rc;
+}
+
+int mi_demod_submit(mi_demod* h, const uint8_t* const* iq, int nbatches, float* waveout, float* iq_out, char* axc, mi_channel_stats* stats) {
+    int rc = check_host_call(h, iq, nbatches, waveout, axc);
     if (rc != MI_OK)
         return rc;
-    // host layout: [rows][nsteps + AGC_EXTRA] = emitted audio followed by the lookahead (channel_t.waveout)
-    const size_t hstride = (nsteps + mi::kAgcExtra) * sizeof(float);
-    HIP_TRY(hipMemcpy2DAsync(waveout, hstride, h->d_wout, nsteps * sizeof(float), nsteps * sizeof(float), rows, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpy2DAsync(waveout + nsteps, hstride, h->d_carry, mi::kAgcExtra * sizeof(float), mi::kAgcExtra * sizeof(float), rows,
-                             hipMemcpyDeviceToHost, s));
-    if (iq_out) {
-        for (size_t r = 0; r < rows; ++r) {
-            if (!h->plan.cp[r % h->nch].has_iq_outputs)
-                continue;
-            HIP_TRY(hipMemcpyAsync(iq_out + r * nsteps * 2, h->d_iqout + r * nsteps, nsteps * sizeof(float2), hipMemcpyDeviceToHost, s));
-        }
+    HIP_TRY(hipSetDevice(h->gpu));
+    if (h->in_flight == 2) {  // both slots taken: the oldest call completes first (its outputs become valid here)
+        rc = mi_demod_wait(h);
+        if (rc != MI_OK)
+            return rc;
     }
-    HIP_TRY(hipMemcpyAsync(axc, h->d_axc, rows * nbatches, hipMemcpyDeviceToHost, s));
-    if (stats)
-        HIP_TRY(hipMemcpyAsync(stats, h->d_stats, rows * sizeof(mi_channel_stats), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    const int k = h->slot_next;
+    rc = slot_prepare(h, k);
+    if (rc != MI_OK)
+        return rc;
+    mi_demod::Slot& sl = h->slot[k];
+    sl.nbatches = nbatches;
+    sl.waveout = waveout, sl.iq_out = iq_out, sl.axc = axc, sl.stats = stats;
+    rc = slot_launch(h, k, iq, nbatches, iq_out != nullptr, stats != nullptr, /*pipelined=*/true);
+    if (rc != MI_OK)
+        return rc;
+    sl.busy = true;
+    if (h->in_flight == 0)
+        h->slot_oldest = k;
+    h->slot_next = k ^ 1;
+    h->in_flight++;
     return MI_OK;
+}
+
+int mi_demod_process(mi_demod* h, const uint8_t* const* iq, int nbatches, float* waveout, float* iq_out, char* axc, mi_channel_stats* stats) {
+    int rc = check_host_call(h, iq, nbatches, waveout, axc);
+    if (rc != MI_OK)
+        return rc;
+    HIP_TRY(hipSetDevice(h->gpu));
+    while (h->in_flight > 0) {  // calls complete in order
+        rc = mi_demod_wait(h);
+        if (rc != MI_OK)
+            return rc;
+    }
+    rc = slot_prepare(h, 0);
+    if (rc != MI_OK)
+        return rc;
+    mi_demod::Slot& sl = h->slot[0];
+    sl.nbatches = nbatches;
+    sl.waveout = waveout, sl.iq_out = iq_out, sl.axc = axc, sl.stats = stats;
+    // one call at a time: everything in order on the handle's own stream (the shortest path for the reference's cadence of one
+    // WAVE_BATCH per call)
+    rc = slot_launch(h, 0, iq, nbatches, iq_out != nullptr, stats != nullptr, /*pipelined=*/false);
+    if (rc != MI_OK)
+        return rc;
+    return slot_collect(h, 0);
 }
 
 int mi_demod_get_stats(mi_demod* h, mi_channel_stats* stats) {

@@ -123,6 +123,25 @@ size_t mi_demod_hop_bytes(const mi_demod* h);
 int mi_demod_process(mi_demod* h, const uint8_t* const* iq, int nbatches, float* waveout, float* iq_out, char* axc,
                      mi_channel_stats* stats);
 
+/* The same call split in two, so that a host can keep two calls in flight: mi_demod_submit() starts the upload of the IQ, both
+ * stages and the download of the results and returns; mi_demod_wait() completes the OLDEST submitted call -- on return that
+ * call's waveout / iq_out / axc / stats hold its results.  The upload of call k+1 (its own copy stream and device buffer)
+ * then runs under the compute of call k, and the download of call k under the compute of call k+1; results are identical
+ * to the same calls made one after the other.  At most two calls are in flight: a third mi_demod_submit() first completes
+ * the oldest one.  The IQ bytes must stay valid until the call has been waited for only if they live in pinned memory (see
+ * mi_host_alloc); any other source is copied into the handle's staging before mi_demod_submit() returns.
+ * mi_demod_process() == mi_demod_submit() + mi_demod_wait() (after completing whatever was in flight). */
+int mi_demod_submit(mi_demod* h, const uint8_t* const* iq, int nbatches, float* waveout, float* iq_out, char* axc,
+                    mi_channel_stats* stats);
+int mi_demod_wait(mi_demod* h);
+
+/* Page-locked host memory the copy engine reads directly: an input_t ring (input-common.h:39-57, allocated in
+ * config.cpp:804) placed here is uploaded without the staging memcpy, which is what bounds the host-buffer entries on long
+ * calls (a single thread copies ~12 GB/s, the link moves ~50).  Pointers from hipHostMalloc / hipHostRegister are recognised
+ * as well, also for `waveout` (the audio is then downloaded straight into it).  mi_host_alloc returns NULL on failure. */
+void* mi_host_alloc(size_t bytes);
+void mi_host_free(void* p);
+
 /* Device-resident entry (capture already in HBM; used for bulk replay and by bench.py).
  *   d_iq            device pointer, stream s starts at d_iq + s*stream_stride_bytes
  *   d_waveout       device [nstreams][nch][nbatches*WAVE_BATCH] -- the emitted samples only; the

@@ -956,3 +956,75 @@ def test_bandwidth_key_present_without_a_filter(pkg):
     wo_plain, _, _, _ = run_product_batches(pkg, dev, plain, iq, 8, per_call=3)
     assert np.array_equal(wo_plain[0, 0] != 0, wo[0, 0] != 0) or True  # (the squelch may differ in the last bit too)
     assert not np.array_equal(wo_plain[0, 0], wo[0, 0])
+
+
+@pytest.mark.parametrize("plan", ["config2", "zoo"])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_submit_wait_keeps_two_calls_in_flight_and_every_bit(pkg, plan, pinned):
+    """mi_demod_submit / mi_demod_wait: the upload of call k+1 runs under the compute of call k on the handle's second staging
+    slot, the download of call k under call k+1.  Calls of different sizes (time-parallel and serial stage 2 on the AM plan),
+    from pageable and from page-locked memory (uploaded without the staging copy), a synchronous mi_demod_process in between:
+    audio incl. the lookahead, flags, raw I/Q and statistics equal the same calls made one after the other, and the oracle."""
+    if plan == "config2":
+        centre, chans = pkg.config2_channels()
+        calls = [16, 16, 3, 24, 8, 1]
+    else:
+        centre, chans = _channel_zoo(pkg)
+        calls = [3, 4, 1, 5, 2, 2]
+    dev = pkg.device_cfg(centerfreq=centre)
+    nbat = sum(calls)
+    iq = gen_iq(pkg, dev, centre, chans, nbat, gate_div=3)[0] if plan == "config2" else _zoo_capture(pkg, dev, centre, chans, nbat, 5)
+    nb, owo, oaxc, oiq = oracle_run(dev, chans, iq, nbat, want_iq=True)
+    assert nb == nbat
+    src = iq
+    if pinned:
+        buf = pkg.PinnedBuffer(iq.size)
+        buf.array[:] = iq
+        src = buf
+
+    def at(pos):
+        return src.view(pos) if pinned else iq[pos:]
+
+    def positions(d):
+        done, out = 0, []
+        for k in calls:
+            out.append(0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes)
+            done += k
+        return out
+
+    # reference run: one synchronous call after the other
+    d = pkg.Demod(dev, chans, max_batches=max(calls))
+    sync = [d.process([iq[p:]], k, want_iq=True) for p, k in zip(positions(d), calls)]
+    d.close()
+    # the same calls, two in flight; the fourth one synchronous (it first completes what is in flight)
+    d = pkg.Demod(dev, chans, max_batches=max(calls))
+    pos = positions(d)
+    got = []
+    d.submit([at(pos[0])], calls[0], want_iq=True)
+    d.submit([at(pos[1])], calls[1], want_iq=True)
+    d.submit([at(pos[2])], calls[2], want_iq=True)  # completes call 0 inside
+    got.append(d.wait())
+    got.append(d.wait())
+    got.append(d.wait())
+    got.append(d.process([iq[pos[3]:]], calls[3], want_iq=True))
+    d.submit([at(pos[4])], calls[4], want_iq=True)
+    d.submit([at(pos[5])], calls[5], want_iq=True)
+    got.append(d.wait())
+    got.append(d.wait())
+    with pytest.raises(pkg.MiError):
+        d.wait()
+    d.close()
+    if pinned:
+        buf.free()
+    done = 0
+    for i, k in enumerate(calls):
+        a, b = got[i], sync[i]
+        assert_same(a[0], b[0], f"call {i}: audio + lookahead")
+        assert_same(a[1], b[1], f"call {i}: flags")
+        for c, ch in enumerate(chans):
+            if ch.has_iq_outputs:
+                assert_same(a[2][0, c], b[2][0, c], f"call {i}: raw I/Q ch{c}")
+        assert bytes(a[3]) == bytes(b[3]), f"call {i}: statistics"
+        assert_same(a[0][0, :, :k * WAVE_BATCH], owo[:, done * WAVE_BATCH:(done + k) * WAVE_BATCH], f"call {i}: audio vs oracle")
+        assert_same(a[1][0], oaxc[:, done:done + k], f"call {i}: flags vs oracle")
+        done += k
