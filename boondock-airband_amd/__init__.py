@@ -97,6 +97,7 @@ ABI_SYMBOLS = [
     "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_last_stage1", "mi_demod_tp_debug", "mi_demod_kernel_time", "mi_demod_kernel_time_prev", "mi_demod_set_option", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
     "mi_plan_window", "mi_plan_twiddles", "mi_plan_levels", "mi_plan_sincos_lut", "mi_plan_channel", "mi_plan_ctcss_coeffs",
     "mi_iqgen_host", "mi_iqgen_device", "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_is_stereo", "mi_mixer_process_device",
+    "mi_gather_unique_id", "mi_gather_create", "mi_gather_destroy", "mi_gather_audio", "mi_gather_stream_wait", "mi_gather_sync",
 ]
 
 _lib = None
@@ -121,6 +122,12 @@ def lib():
         L.mi_host_alloc.restype = vp
         L.mi_host_free.argtypes = [vp]
         L.mi_host_free.restype = None
+        L.mi_gather_unique_id.argtypes = [vp]
+        L.mi_gather_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(vp)]
+        L.mi_gather_destroy.argtypes = [vp]
+        L.mi_gather_audio.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+        L.mi_gather_stream_wait.argtypes = [vp, vp]
+        L.mi_gather_sync.argtypes = [vp]
         L.mi_demod_destroy.restype = None
         for f in (L.mi_demod_bytes_needed, L.mi_demod_bytes_consumed):
             f.argtypes = [vp, C.c_int]
@@ -411,6 +418,36 @@ def iqgen_host(cfg, stream_id, first, count):
 
 def iqgen_device(cfg, first_stream_id, nstreams, stream_stride, first, count, d_out_ptr, hip_stream=None):
     _check(lib().mi_iqgen_device(C.byref(cfg), first_stream_id, nstreams, stream_stride, first, count, d_out_ptr, hip_stream))
+
+
+class Gather:
+    """mi_gather_*: audio + flags of every rank to rank 0 over RCCL (the C-ABI twin of shard.AudioGather)."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        _check(lib().mi_gather_unique_id(C.byref(buf)))
+        return bytes(buf)
+
+    def __init__(self, uid, rank, world, gpu, streams_per_rank, nch, max_batches):
+        self._h = C.c_void_p()
+        idbuf = (C.c_char * 128).from_buffer_copy(uid) if uid is not None else None
+        arr = (C.c_int * world)(*streams_per_rank)
+        _check(lib().mi_gather_create(None if idbuf is None else C.byref(idbuf), rank, world, gpu, arr, nch, max_batches, C.byref(self._h)))
+
+    def audio(self, d_waveout, d_axc, nbatches, d_all_waveout=None, d_all_axc=None, open_only=False, hip_stream=None):
+        _check(lib().mi_gather_audio(self._h, d_waveout, d_axc, nbatches, 1 if open_only else 0, d_all_waveout, d_all_axc, hip_stream))
+
+    def stream_wait(self, hip_stream=None):
+        _check(lib().mi_gather_stream_wait(self._h, hip_stream))
+
+    def sync(self):
+        _check(lib().mi_gather_sync(self._h))
+
+    def close(self):
+        if self._h:
+            lib().mi_gather_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 class PinnedBuffer:

@@ -303,6 +303,32 @@ int mi_mixer_is_stereo(const mi_mixer* m);
 int mi_mixer_process_device(mi_mixer* m, const float* d_waveout, size_t row_stride, const char* d_axc, size_t axc_stride, int nbatches,
                             float* d_left, float* d_right, char* d_axc_out, void* hip_stream);
 
+/* ---------------- multi-GPU: gather of audio + flags to rank 0 ----------------
+ * One process per GPU; device streams are independent (one demod thread per device in the reference,
+ * rtl_airband.cpp:1044-1078) and are partitioned stream-major over the ranks; nothing crosses GPUs except this gather, which
+ * brings every rank's decimated audio and axcindicate flags to rank 0, where the reference's output / mixer threads run
+ * (output.cpp:899-961).  RCCL point-to-point on the gather's own stream (librccl.so.1 is loaded on first use).
+ *   mi_gather_unique_id   rank 0 makes the 128-byte id; the host program hands it to every rank (its launcher's channel)
+ *   mi_gather_create      streams_per_rank[world]; max_batches bounds nbatches of a step
+ *   mi_gather_audio       one step, every rank: d_waveout [streams_local][nch][nbatches*WAVE_BATCH], d_axc [streams_local][nch][nbatches]
+ *                         as mi_demod_process_device wrote them on `hip_stream`; on rank 0 the job-wide arrays
+ *                         d_all_waveout [streams_total][nch][nbatches*WAVE_BATCH], d_all_axc [streams_total][nch][nbatches] (ignored elsewhere).
+ *                         Asynchronous: it starts when `hip_stream` reaches this point and runs on the gather's stream beside
+ *                         whatever the caller enqueues next; do not overwrite its inputs / read its outputs before
+ *                         mi_gather_stream_wait (makes a stream wait for it) or mi_gather_sync (the host waits).
+ *                         open_only != 0: only the (row, batch) blocks whose flag is not MI_NO_SIGNAL travel -- what the reference's
+ *                         non-continuous outputs consume (output.cpp:518,568) -- and rank 0 gets zeros for the others; this mode
+ *                         synchronises the gather's stream with the host once per step (it needs the block counts). */
+typedef struct { char internal[128]; } mi_gather_id;
+typedef struct mi_gather mi_gather;
+int mi_gather_unique_id(mi_gather_id* id);
+int mi_gather_create(const mi_gather_id* id, int rank, int world, int gpu, const int* streams_per_rank, int nch, int max_batches, mi_gather** out);
+void mi_gather_destroy(mi_gather* g);
+int mi_gather_audio(mi_gather* g, const float* d_waveout, const char* d_axc, int nbatches, int open_only, float* d_all_waveout, char* d_all_axc,
+                    void* hip_stream);
+int mi_gather_stream_wait(mi_gather* g, void* hip_stream);
+int mi_gather_sync(mi_gather* g);
+
 #ifdef __cplusplus
 }
 #endif
