@@ -235,6 +235,16 @@ def kernel_table(res):
     return kernels
 
 
+def traffic_of(traffic, name):
+    """PMC bytes per launch of a bench kernel name; stage 1 runs as l64_entry (the plan-compiled lane-resident kernel),
+    k_channelize9p or k_channelize<...> depending on the plan and the options."""
+    b = name.split("#")[0]
+    for k in ((b, "l64_entry", b + "9p") if b == "k_channelize" else (b,)):
+        if k in traffic:
+            return traffic[k]
+    return None
+
+
 def roofline_block(res, kernels, traffic, traffic_src):
     nch, n_iq, n = res["nch"], res["n_iq"], 1 << res["fft_log"]
     path_bytes_per_sample = 2.0 + (4.0 * nch + 8.0 * n_iq) / HOP  # SURVEY 8(d): 2.2 B/sample @ 8 ch, 2.8 @ 32 ch
@@ -253,7 +263,7 @@ def roofline_block(res, kernels, traffic, traffic_src):
     path_gbs = sps * path_bytes_per_sample / step_s / 1e9
     tflops = sps * flop_per_sample / step_s / 1e12
     return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic.get(dom.split("#")[0], traffic.get(dom.split("#")[0] + "9p")), "traffic_source": traffic_src,
+            "traffic": traffic_of(traffic, dom), "traffic_source": traffic_src,
             "definition": "achieved = SURVEY 8(d) algorithmic bytes per sample (path_bytes_per_sample) x samples per launch / the dominant "
                           "kernel's mean launch duration (HIP events on its launch stream)",
             "path_bytes_per_sample": path_bytes_per_sample,
@@ -332,8 +342,7 @@ def main():
             traffic_src = (f"profiles/{PMC_PROFILE} (sha1 {sha}): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command "
                            f"(tools/make_profiles.sh), FETCH_SIZE x2 (gfx950); not re-measured inside this run")
         for name, k in kernels.items():
-            b = name.split("#")[0]
-            k["traffic"] = traffic.get(b, traffic.get(b + "9p"))  # k_channelize9p: the pruned N = 512 instantiation
+            k["traffic"] = traffic_of(traffic, name)
         nch, nstreams = res["nch"], res["nstreams"]
         out = {
             "metric": f"IQ MS/s processed (x real-time) @ {nch}ch fft_size={1 << res['fft_log']}",
