@@ -116,11 +116,14 @@ hipError_t launch_afc(const AfcArgs& a, hipStream_t s);
 hipError_t launch_move_head(float* dst, const float* src, size_t plane_stride, int rows, hipStream_t s);
 
 // ---- time-parallel stage 2 (tp.hip) ----
-constexpr uint32_t TP_L = 512;      // steps per segment
-constexpr uint32_t TP_W = 4096;     // warm-up of the state machine / AGC before a segment (multiple of TP_L)
-constexpr uint32_t TP_L1 = 512;     // steps per lane of the full_ sandwich pass
-constexpr uint32_t TP_W1 = 3072;    // its warm-up: 0.99^3072 = 4e-14 closes the sandwich over 10^6 of dynamic range (unclosed blocks are flagged invalid)
-constexpr int TP_MAXEV = 4;         // close-edge fades per segment (they are >= 197 steps apart: at most 3)
+// Steps per segment (TpArgs::L): 512 .. 4096, a power of two, chosen per handle from its row count.  One stream x 8 channels
+// needs short segments to find any parallelism at all (512: 2000 lanes per minute and channel, each paying TP_W steps of
+// warm-up for 512 of work); hundreds of rows have parallelism to spare, and a 2048-step segment pays the same warm-up for
+// four times the work.
+constexpr uint32_t TP_L_MIN = 512, TP_L_MAX = 4096;
+constexpr uint32_t TP_W = 4096;     // warm-up of the state machine / AGC before a segment (a multiple of every segment length)
+constexpr uint32_t TP_W1 = 3072;    // warm-up of the full_ sandwich pass: 0.99^3072 = 4e-14 closes the sandwich over 10^6 of dynamic range (unclosed blocks are flagged invalid)
+constexpr int TP_MAXEV = 24;        // close-edge fades per segment (they are >= 197 steps apart: at most 21 in 4096 steps)
 constexpr uint32_t TP_MAXCHAIN = 32;
 constexpr int TP_NREC = 19 + TP_MAXEV;
 
@@ -140,7 +143,8 @@ struct TpArgs {
     const int* rows;  // handle rows (stream*nch + ch) taking this path
     int nrows, nch;
     uint32_t nsteps, nbatches, nblk, nseg;  // totals of the call (array strides)
-    // The call is processed in chunks (multiples of lcm(TP_L, WAVE_BATCH) = 64000 steps) so that the serial core
+    uint32_t L;                             // steps per segment and per lane of the full_ sandwich pass (TP_L_MIN .. TP_L_MAX)
+    // The call is processed in chunks (multiples of lcm(L, WAVE_BATCH) steps: 64000 at L = 512) so that the serial core
     // chain of chunk i+1 overlaps the parallel passes of chunk i on another HIP stream.  Absolute ranges:
     uint32_t step0, step1, seg0, seg1, blk0, blk1, bat0, bat1;
     int first_chunk, last_chunk;
@@ -170,7 +174,9 @@ struct TpArgs {
     int* diag;                                 // [nrows][4] segments not accepted in scan 0..3, then [nrows][4] core-chain block counts
     int seg_lpw;                               // lanes per wave of k_tp_seg, 0 = auto (MI_OPT_TP_SEG_LANES)
 };
-constexpr uint32_t TP_CHUNK_UNIT = 64000;  // lcm(TP_L = 512, WAVE_BATCH = 2000)
+inline uint32_t tp_chunk_unit(uint32_t L) {  // lcm(L, WAVE_BATCH = 2000) for L = 2^k >= 16: 2000 = 16 * 125
+    return L * 125u;
+}
 
 // One chunk in three parts so the caller can put the serial part on its own stream:
 hipError_t launch_tp_front(const TpArgs& a, hipStream_t s, bool seed_chain);       // (chain seed on the first chunk) + k_tp_full

@@ -179,6 +179,8 @@ struct mi_demod {
     int* d_diag = nullptr;
     uint32_t last_nseg[kSets] = {};
     size_t tp_max_blk = 0, tp_max_seg = 0;
+    uint32_t tp_L = 512;  // steps per segment (kernels.hpp, TP_L_MIN .. TP_L_MAX), fixed when the handle is created
+    int opt_tp_L = 0;     // MI_AIRBAND_TP_SEGMENT at create: 0 = by row count
 };
 
 namespace {
@@ -194,6 +196,8 @@ constexpr int kTpMinBatches = 8;  // below this the segments are too few to pay 
 //   MI_AIRBAND_PRUNE=0       full FFT graph at N = 512 (the pruned one is bit-exact and faster where it applies)
 //   MI_AIRBAND_CONV=lut|arith  u8 conversion through the level table / the arithmetic form the plan has checked against it
 //   MI_AIRBAND_STEADY=0      serial stage 2 takes every step in the sample loop
+//   MI_AIRBAND_TP_SEGMENT=512|1024|2048|4096  steps per segment of the time-parallel path (default: by row count; sizes the scratch,
+//                            so it is read when the handle is created and has no mi_demod_set_option twin)
 //   MI_AIRBAND_L64=0         no lane-resident stage 1 at N = 512 (the pruned / full exchange kernels instead)
 //   MI_AIRBAND_UNI_ROWS=n, MI_AIRBAND_TP_CHUNKS=n, MI_AIRBAND_TP_RATIO=x, MI_AIRBAND_TP_LPW=n
 void tuning_from_env(mi_demod* h) {
@@ -215,6 +219,10 @@ void tuning_from_env(mi_demod* h) {
         h->opt_tp_chunks = std::max(1, std::atoi(e));
     if (const char* e = get("MI_AIRBAND_TP_RATIO"))
         h->opt_tp_ratio = std::max(0.25, std::atof(e));
+    if (const char* e = get("MI_AIRBAND_TP_SEGMENT")) {
+        const int v = std::atoi(e);
+        h->opt_tp_L = (v == 512 || v == 1024 || v == 2048 || v == 4096) ? v : 0;
+    }
     if (const char* e = get("MI_AIRBAND_L64"))
         h->opt_l64 = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_L64_JIT"))
@@ -376,7 +384,9 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         const bool seg_early = overlap && (out_hi <= h->prev_out_lo || out_lo >= h->prev_out_hi);
         const int before_prev = (h->cur + mi_demod::kSets - 1) % mi_demod::kSets;
         const uint32_t n = da.nsteps;
-        const uint32_t units = n / mi::TP_CHUNK_UNIT;
+        const uint32_t L = h->tp_L;
+        const uint32_t chunk_unit = mi::tp_chunk_unit(L);
+        const uint32_t units = n / chunk_unit;
         // Chunk sizes grow geometrically: a short first chunk gets the serial core chain going early (its stage 1 +
         // aggregates are all that precedes it), later chunks are long because every wide pass has a fixed latency per
         // launch.  MI_AIRBAND_TP_CHUNKS / MI_AIRBAND_TP_RATIO override the measured defaults.
@@ -429,7 +439,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.nsteps = n;
         ta.nbatches = da.nbatches;
         ta.nblk = n / 16;
-        ta.nseg = (n + mi::TP_L - 1) / mi::TP_L;
+        ta.L = L;
+        ta.nseg = (n + L - 1) / L;
         ta.mag = planes;
         ta.plane_stride = h->plane_stride;
         ta.wmain = d_wmain;
@@ -461,10 +472,10 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         h->last_nseg[q] = ta.nseg;
         auto chunk = [&](int i) {
             mi::TpArgs c = ta;
-            c.step0 = bound[static_cast<size_t>(i)] * mi::TP_CHUNK_UNIT;
-            c.step1 = (i == C - 1) ? n : bound[static_cast<size_t>(i) + 1] * mi::TP_CHUNK_UNIT;
-            c.seg0 = c.step0 / mi::TP_L;
-            c.seg1 = (c.step1 + mi::TP_L - 1) / mi::TP_L;
+            c.step0 = bound[static_cast<size_t>(i)] * chunk_unit;
+            c.step1 = (i == C - 1) ? n : bound[static_cast<size_t>(i) + 1] * chunk_unit;
+            c.seg0 = c.step0 / L;
+            c.seg1 = (c.step1 + L - 1) / L;
             c.blk0 = c.step0 / 16;
             c.blk1 = c.step1 / 16;
             c.bat0 = c.step0 / mi::kWaveBatch;
@@ -521,7 +532,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             HIP_TRY(hipEventRecord(ev(i, 4), h->aux_stream));
             hipStream_t ss = h->seg_stream[i % mi_demod::kSegStreams];
             // A segment pass needs core(i).  It also has to wait for the previous call (ev_head) where it touches what
-            // that call's tail still owns: the carried ChanState (the lanes of the first TP_W / TP_L + 1 segments start
+            // that call's tail still owns: the carried ChanState (the lanes of the first TP_W / L + 1 segments start
             // from it), the audio lookahead (written by the last segments) and the caller's audio buffer if it is the
             // one the previous call wrote.
             HIP_TRY(hipStreamWaitEvent(ss, ev(i, 4), 0));
@@ -529,7 +540,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
                 HIP_TRY(hipStreamWaitEvent(ss, h->ev[before_prev][2], 0));
             // (events 5 -> 12 time the pass itself: they sit inside every wait of the segment stream; of a split first chunk
             // the body is timed, its few head segments are not)
-            const uint32_t head_end = std::min<uint32_t>(c.seg1, mi::TP_W / mi::TP_L + 1);
+            const uint32_t head_end = std::min<uint32_t>(c.seg1, mi::TP_W / L + 1);
             if (!seg_early || c.last_chunk) {
                 HIP_TRY(hipStreamWaitEvent(ss, h->ev_head, 0));
                 HIP_TRY(hipEventRecord(ev(i, 5), ss));
@@ -855,7 +866,13 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
         TRY_OR_BAIL(dalloc(&h->d_afc_spec, static_cast<size_t>(nstreams) * p.fft_size));
     if (h->tp_eligible) {
         h->tp_max_blk = max_steps / 16;
-        h->tp_max_seg = (max_steps + mi::TP_L - 1) / mi::TP_L;
+        // segment length of the time-parallel path: short segments where rows are few (the parallelism has to come from time),
+        // long ones where they are many (each lane pays TP_W steps of warm-up whatever its segment's length)
+        if (h->opt_tp_L == 0)
+            h->tp_L = h->rows <= 32 ? 512u : (h->rows <= 128 ? 1024u : 2048u);
+        else
+            h->tp_L = static_cast<uint32_t>(h->opt_tp_L);
+        h->tp_max_seg = (max_steps + h->tp_L - 1) / h->tp_L;
         std::vector<int> ident(rows);
         for (size_t i = 0; i < rows; ++i)
             ident[i] = static_cast<int>(i);

@@ -19,7 +19,7 @@
 //                                capped stays cap (the reference's own shortcut, squelch.cpp:509-510);
 //                     STEP       otherwise: the 16 samples are stepped one by one.
 //                   It stores the exact core state at every segment boundary.
-//  B   k_tp_seg     one lane per (channel, segment of TP_L steps): the complete state machine + AM AGC + audio,
+//  B   k_tp_seg     one lane per (channel, segment of L = 512 .. 4096 steps): the complete state machine + AM AGC + audio,
 //                   started TP_W steps early from the exact core state and a GUESSED state-machine/AGC state
 //                   (idle CLOSED).  It records the state it had at its segment start (S), runs the segment
 //                   writing audio, and records its end state (E).  Dead fields are canonicalised.
@@ -79,15 +79,15 @@ __device__ __forceinline__ float level_of(const ChanParams& p, const float nf, c
 // P1: pre_filter_.full_ by sandwich, and the per-block aggregates
 // =====================================================================================================
 __global__ __launch_bounds__(64) void k_tp_full(const TpArgs a) {
-    const int lanes_per_row = (a.step1 - a.step0 + TP_L1 - 1) / TP_L1;  // this chunk's lanes
+    const int lanes_per_row = (a.step1 - a.step0 + a.L - 1) / a.L;  // this chunk's lanes
     const int gid = blockIdx.x * 64 + threadIdx.x;
     if (gid >= a.nrows * lanes_per_row)
         return;
     const int r = gid / lanes_per_row, q = gid - r * lanes_per_row;
     const int row = a.rows[r];
     const float* __restrict__ x = a.mag + static_cast<size_t>(row) * a.plane_stride + kAgcExtra;
-    const uint32_t t0 = a.step0 + static_cast<uint32_t>(q) * TP_L1;
-    const uint32_t t1 = min(t0 + TP_L1, a.step1);
+    const uint32_t t0 = a.step0 + static_cast<uint32_t>(q) * a.L;
+    const uint32_t t1 = min(t0 + a.L, a.step1);
     const uint32_t tw = t0 > TP_W1 ? t0 - TP_W1 : 0;
     float lo, hi;
     if (tw == 0 && !a.prev_mag) {
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
     // the chain state comes from the previous chunk's core kernel (k_tp_prologue seeds it from the carried ChanState)
     float nf = a.core_carry[r].nf, cap = a.core_carry[r].cap, c = a.core_carry[r].c, full = a.core_carry[r].full;
     const uint32_t nblk = a.blk1;
-    constexpr uint32_t bps = TP_L / 16;  // blocks per segment
+    const uint32_t bps = a.L / 16;  // blocks per segment
 
     int n_run = 0, n_single = 0, n_step = 0, n_fail = 0;  // diagnostics: blocks per path, failed hypotheses
     CoreGroup nxt = core_load(a, x, bbase, a.blk0, lane);
@@ -637,7 +637,7 @@ __device__ __forceinline__ float tp_step(TpLane& s, const ChanParams& p, const u
         else if (wout < -1.0f)
             wout = -1.0f;
         if (in_seg)
-            s.open_mask |= ((i / kWaveBatch) == batch0) ? 1 : 2;
+            s.open_mask |= 1 << (i / kWaveBatch - batch0);
     }
     return wout;
 }
@@ -739,7 +739,7 @@ __device__ __forceinline__ void tp_chunk(TpLane& s, const ChanParams& p, const T
                         wout = -1.0f;
                     wv[k] = wout;
                     if (in_seg)
-                        s.open_mask |= (((i + k) / kWaveBatch) == batch0) ? 1 : 2;
+                        s.open_mask |= 1 << ((i + k) / kWaveBatch - batch0);
                 }
                 if (in_seg)
                     s.uses_agc = 1;
@@ -1000,7 +1000,7 @@ __device__ __forceinline__ void tp_block(TpLane& s, const ChanParams& p, const T
                 if (!wait_opening) {
                     s.agc = agc;
                     if (kInSeg) {
-                        s.open_mask |= ((i / kWaveBatch) == batch0) ? 1 : 2;  // 2000 = 125 blocks: a block lies in one batch
+                        s.open_mask |= 1 << (i / kWaveBatch - batch0);  // 2000 = 125 blocks: a block lies in one batch
                         s.uses_agc = 1;
                     }
                 }
@@ -1091,8 +1091,9 @@ __global__ __launch_bounds__(64) void k_tp_seg(const TpArgs a) {
     const int row = a.rows[r];
     const ChanParams p = a.cp[row % a.nch];
     const float* __restrict__ magrow = a.mag + static_cast<size_t>(row) * a.plane_stride;
-    const uint32_t s0 = k * TP_L, s1 = min(s0 + TP_L, a.nsteps);
-    const uint32_t wk = k > TP_W / TP_L ? k - TP_W / TP_L : 0;  // boundary index where the warm-up starts
+    const uint32_t s0 = k * a.L, s1 = min(s0 + a.L, a.nsteps);
+    const uint32_t wsegs = TP_W / a.L;
+    const uint32_t wk = k > wsegs ? k - wsegs : 0;  // boundary index where the warm-up starts
     TpLane s;
     seg_reset(s);
     if (wk == 0) {  // from the true state at the start of the call
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(64) void k_tp_seg(const TpArgs a) {
         s.agc = 0.5f;
     }
     load_core(s, p, a.core[static_cast<size_t>(r) * (a.nseg + 1) + wk]);
-    tp_run<false>(s, p, a, r, row, magrow, wk * TP_L, s0, 0, static_cast<size_t>(r) * a.nseg + k);
+    tp_run<false>(s, p, a, r, row, magrow, wk * a.L, s0, 0, static_cast<size_t>(r) * a.nseg + k);
     const TpFsm S = canon(s);
     const float s_agc = s.agc;
     seg_reset(s);
@@ -1271,7 +1272,7 @@ __device__ __forceinline__ void rerun_chain(const TpArgs& a, const int r, const 
             if (same(canon(s), S) && (!uses || sagc == __float_as_int(s.agc)))
                 return;
         }
-        const uint32_t s0 = k * TP_L, s1 = min(s0 + TP_L, a.nsteps);
+        const uint32_t s0 = k * a.L, s1 = min(s0 + a.L, a.nsteps);
         if (kStateOnly) {
             int* __restrict__ ts = a.tstart + (base + k) * 8;
             ts[0] = s.cur, ts[1] = s.next, ts[2] = s.delay, ts[3] = s.low, ts[4] = s.recent, ts[5] = s.closed;
@@ -1310,7 +1311,7 @@ __device__ __forceinline__ void redo_segment(const TpArgs& a, const int r, const
     seg_reset(s);
     lane_from_tstart(s, a.tstart + (base + k) * 8);
     load_core(s, p, a.core[static_cast<size_t>(r) * (a.nseg + 1) + k]);
-    const uint32_t s0 = k * TP_L, s1 = min(s0 + TP_L, a.nsteps);
+    const uint32_t s0 = k * a.L, s1 = min(s0 + a.L, a.nsteps);
     const TpFsm S = canon(s);
     const float s_agc = s.agc;
     seg_reset(s);
@@ -1413,12 +1414,11 @@ __global__ __launch_bounds__(64) void k_tp_finish(const TpArgs a) {
     // axcindicate per WAVE_BATCH from the segments' open masks
     int nopen = 0;
     for (uint32_t b = a.bat0 + lane; b < a.bat1; b += 64) {
-        const uint32_t kmin = (b * kWaveBatch) / TP_L, kmax = min((b * kWaveBatch + kWaveBatch - 1) / TP_L, a.nseg - 1);
+        const uint32_t kmin = (b * kWaveBatch) / a.L, kmax = min((b * kWaveBatch + kWaveBatch - 1) / a.L, a.nseg - 1);
         bool open = false;
         for (uint32_t k = kmin; k <= kmax; ++k) {
             const int m = a.rec[17 * a.rec_stride + base + k];
-            const bool first = ((k * TP_L) / kWaveBatch) == b;
-            open |= first ? (m & 1) != 0 : (m & 2) != 0;
+            open |= ((m >> (b - (k * a.L) / kWaveBatch)) & 1) != 0;  // bit j of a segment's mask: its (j+1)-th batch
         }
         a.axc[static_cast<size_t>(row) * a.nbatches + b] = open ? MI_SIGNAL : MI_NO_SIGNAL;
         nopen += open ? 1 : 0;
@@ -1429,7 +1429,7 @@ __global__ __launch_bounds__(64) void k_tp_finish(const TpArgs a) {
     if (lane != 0)
         return;
     const TpFinal f = a.fin[r];
-    const TpCore t = a.core[static_cast<size_t>(r) * (a.nseg + 1) + (a.blk1 + TP_L / 16 - 1) / (TP_L / 16)];  // end of this chunk
+    const TpCore t = a.core[static_cast<size_t>(r) * (a.nseg + 1) + (a.blk1 + a.L / 16 - 1) / (a.L / 16)];  // end of this chunk
     const ChanParams p = a.cp[row % a.nch];
     ChanState cs = a.st[row];
     cs.noise_floor = t.nf;
@@ -1527,7 +1527,7 @@ hipError_t launch_tp_front(const TpArgs& a, hipStream_t s, bool seed_chain) {
     } else if (a.first_chunk) {
         TP_LAUNCH(k_tp_fullbound, (a.nrows + 255) / 256, 256);
     }
-    const int lanes1 = a.nrows * static_cast<int>((a.step1 - a.step0 + TP_L1 - 1) / TP_L1);
+    const int lanes1 = a.nrows * static_cast<int>((a.step1 - a.step0 + a.L - 1) / a.L);
     TP_LAUNCH(k_tp_full, (lanes1 + 63) / 64, 64);
     return hipSuccess;
 }

@@ -173,7 +173,7 @@ enum { MI_STAGE1_EXCHANGE_FULL = 0, MI_STAGE1_EXCHANGE_PRUNED = 1, MI_STAGE1_LAN
 int mi_demod_last_stage1(mi_demod* h, int* kind);
 
 /* Diagnostics of the time-parallel path after a call that took it (synchronises): the exact Squelch core
- * state {noise_floor_, moving_avg_cap_, pre_filter_.capped_, pre_filter_.full_} before each 512-step segment
+ * state {noise_floor_, moving_avg_cap_, pre_filter_.capped_, pre_filter_.full_} before each segment (512 .. 4096 steps, by row count)
  * (core4: [nseg+1][4]) and diag8[0..3] = segments not accepted in verification scans 0..3 (scan 3 runs after the
  * serial fallback and is always 0; diag4[2] != 0 means the fallback had to run). */
 int mi_demod_tp_debug(mi_demod* h, int row, float* core4, int max_entries, int* diag8, int* nseg);

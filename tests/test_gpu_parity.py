@@ -1028,3 +1028,64 @@ def test_submit_wait_keeps_two_calls_in_flight_and_every_bit(pkg, plan, pinned):
         assert_same(a[0][0, :, :k * WAVE_BATCH], owo[:, done * WAVE_BATCH:(done + k) * WAVE_BATCH], f"call {i}: audio vs oracle")
         assert_same(a[1][0], oaxc[:, done:done + k], f"call {i}: flags vs oracle")
         done += k
+
+
+@pytest.mark.parametrize("seg", [1024, 2048, 4096])
+def test_time_parallel_segment_lengths_keep_every_bit(pkg, monkeypatch, seg):
+    """The time-parallel path cuts a row into segments of 512 .. 4096 steps (short where rows are few, long where they are
+    many: every lane pays the same 4096-step warm-up).  Forced here on one stream x 8 AM channels: consecutive calls of
+    different sizes (a segment then spans up to three WAVE_BATCHes and holds up to 21 close-edge fades; the last segment of a
+    call is partial; calls shorter than the warm-up start every lane from the carried state), audio, flags and statistics
+    equal the oracle's and every segment ends up verified."""
+    monkeypatch.setenv("MI_AIRBAND_TP_SEGMENT", str(seg))
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    calls = [40, 9, 64, 16]
+    nbat = sum(calls)
+    iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=5)  # 0.2 s on / 0.2 s off: many edges per segment
+    nb, owo, oaxc, _ = oracle_run(dev, chans, iq, nbat)
+    assert nb == nbat
+    wo, axc, st, paths = _tp_run(pkg, dev, chans, iq, calls, monkeypatch)
+    assert paths == [(1, 0)] * len(calls)
+    assert_same(axc[0], oaxc, f"axcindicate, segments of {seg}")
+    assert_same(wo[0], owo, f"audio, segments of {seg}")
+    assert st[0].open_count >= 10
+
+
+def test_time_parallel_many_rows_take_long_segments_and_equal_the_oracle(pkg, monkeypatch):
+    """48 streams x 8 AM channels = 384 rows pick 2048-step segments by themselves; two overlapping calls through the device
+    entry, every stream against the oracle."""
+    import torch
+    monkeypatch.delenv("MI_AIRBAND_TP", raising=False)
+    monkeypatch.delenv("MI_AIRBAND_TP_SEGMENT", raising=False)
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    nstreams, calls = 48, [16, 24]
+    nbat = sum(calls)
+    nbytes = (bytes_for_batches(dev, nbat) + 255) // 256 * 256
+    gcfg = pkg.iqgen_cfg(sample_rate=dev.sample_rate, gate_samples=dev.sample_rate // 3, carriers=pkg.carriers_for(centre, chans))
+    d_iq = torch.zeros((nstreams, nbytes), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    pkg.iqgen_device(gcfg, 0, nstreams, nbytes, 0, nbytes // 2, d_iq.data_ptr(), s)
+    torch.cuda.synchronize()
+    iq_host = d_iq.cpu().numpy()
+    d = pkg.Demod(dev, chans, nstreams=nstreams, max_batches=max(calls))
+    d.set_option(pkg.OPT_EARLY_INPUT, 1)
+    outs, done = [], 0
+    for k in calls:
+        pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+        wo = torch.empty((nstreams, len(chans), k * WAVE_BATCH), dtype=torch.float32, device="cuda")
+        ax = torch.empty((nstreams, len(chans), k), dtype=torch.uint8, device="cuda")
+        d.process_device(d_iq.data_ptr() + pos, nbytes, k, wo.data_ptr(), ax.data_ptr(), hip_stream=s)
+        outs.append((wo, ax))
+        done += k
+    torch.cuda.synchronize()
+    assert d.last_path() == (1, 0)
+    d.close()
+    wo = torch.cat([o[0] for o in outs], dim=2).cpu().numpy()
+    ax = torch.cat([o[1] for o in outs], dim=2).cpu().numpy()
+    for st in range(0, nstreams, 5):
+        nb, owo, oaxc, _ = oracle_run(dev, chans, iq_host[st], nbat)
+        assert nb == nbat
+        assert_same(ax[st], oaxc, f"flags, stream {st}")
+        assert_same(wo[st], owo, f"audio, stream {st}")
