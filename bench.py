@@ -314,7 +314,7 @@ def main():
     res = run_workload(pkg, args, args.workload, args.steps, args.warmup, gather_mode, rank, world, local_rank)
 
     extra = {}
-    if world > 1 and not args.no_config5 and args.workload == "config2":
+    if (world > 1 or os.environ.get("BENCH_FORCE_CONFIG5") == "1") and not args.no_config5 and args.workload == "config2":
         # BASELINE configs[4] on the same ranks: short runs, outside the timed region of the line's own metric
         saved = (args.streams, args.seconds)
         args.streams, args.seconds = 0, 0.0
