@@ -70,9 +70,10 @@ hipError_t launch_channelize_l64(const ChannelizeArgs& c, int sfmt, int nstreams
     a.ntiles = (c.nfft + mi_l64::kTile - 1) / mi_l64::kTile;
     a.sfmt = sfmt;
     a.linear_tiles = c.l64.linear_tiles;
-    const size_t lds = static_cast<size_t>(a.span_bytes) + 4 * mi_l64::kN + 1024 + 4u * static_cast<size_t>(l64_round_windows(m6)) * a.zstride +
-                       static_cast<size_t>(c.nch) * mi_l64::kTile * 4 + static_cast<size_t>(c.n_iq_rows) * mi_l64::kTile * 8;
-    if (lds > 160 * 1024 || static_cast<unsigned long long>(a.ntiles) * static_cast<unsigned>(nstreams) >= (1ull << 32))
+    // (the exchange buffer of stages 7..9, 4 waves x round windows x zstride, lies over the span)
+    const size_t lds = static_cast<size_t>(a.span_bytes) + 4 * mi_l64::kN + 1024 + static_cast<size_t>(c.nch) * mi_l64::kTile * 4 +
+                       static_cast<size_t>(c.n_iq_rows) * mi_l64::kTile * 8;
+    if (lds > 160 * 1024 || 4u * static_cast<size_t>(l64_round_windows(m6)) * a.zstride > a.span_bytes || static_cast<unsigned long long>(a.ntiles) * static_cast<unsigned>(nstreams) >= (1ull << 32))
         return hipErrorInvalidValue;
     a.nstreams = static_cast<unsigned>(nstreams);
     // persistent workgroups, each walking a contiguous run of tiles: two per CU are resident (LDS), a few more keep the tail short
@@ -83,7 +84,10 @@ hipError_t launch_channelize_l64(const ChannelizeArgs& c, int sfmt, int nstreams
             (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
-    const unsigned long long want = static_cast<unsigned long long>(cus) * (c.l64.wg_per_cu > 0 ? c.l64.wg_per_cu : 4);
+    // a multiple of the workgroups a CU holds at once (3 when the instance was compiled for three waves per SIMD and its LDS
+    // allows it, else 2): a remainder would queue behind the resident ones and leave CUs idle at the end
+    const int resident = (jit && l64_jit_minwaves(jit) >= 3 && lds * 3 <= 160 * 1024) ? 3 : 2;
+    const unsigned long long want = static_cast<unsigned long long>(cus) * (c.l64.wg_per_cu > 0 ? c.l64.wg_per_cu : 2 * resident);
     const unsigned gx = static_cast<unsigned>(ttotal < want ? ttotal : want);
     if (jit)
         return l64_jit_launch(jit, a, gx, 1u, lds, s);

@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +27,7 @@ struct L64Jit {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
     size_t lds_attr = 0;  // dynamic LDS size the function has been told about
+    int minwaves = 2;     // waves per SIMD the instance was compiled for (2 or 3 workgroups per CU)
 };
 
 namespace {
@@ -127,8 +129,13 @@ const L64Jit* l64_jit_get(int device, int hop, const uint64_t need[6], const cha
     std::string arch = "gfx950";
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.gcnArchName[0])
         arch = prop.gcnArchName;
+    // three workgroups per CU (LDS: 50 KB each) where the plan leaves few enough points live; the compiler keeps within the
+    // matching register budget
+    const int live = __builtin_popcountll(need[5]) > 16 ? 2 : 3;
+    const char* mw = std::getenv("MI_AIRBAND_L64_MINWAVES");
+    const int minwaves = (mw && *mw) ? std::max(1, std::min(4, std::atoi(mw))) : live;
     std::vector<std::string> opts = {"--offload-arch=" + arch, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-DMI_L64_JIT=1",
-                                     "-DL64_HOP=" + std::to_string(hop), "-DL64_MINWAVES=2"};
+                                     "-DL64_HOP=" + std::to_string(hop), "-DL64_MINWAVES=" + std::to_string(minwaves)};
     for (int s = 0; s < 6; ++s) {
         char buf[64];
         std::snprintf(buf, sizeof(buf), "-DL64_N%d=0x%llxull", s + 1, static_cast<unsigned long long>(need[s]));
@@ -171,8 +178,13 @@ const L64Jit* l64_jit_get(int device, int hop, const uint64_t need[6], const cha
         (void)hipGetLastError();
         return fail(std::string("loading the compiled kernel failed: ") + hipGetErrorString(he));
     }
+    e->jit.minwaves = minwaves;
     e->usable = true;
     return &e->jit;
+}
+
+int l64_jit_minwaves(const L64Jit* j) {
+    return j ? j->minwaves : 2;
 }
 
 hipError_t l64_jit_launch(const L64Jit* j, const L64Args& a, unsigned gx, unsigned gy, size_t lds, hipStream_t s) {

@@ -205,8 +205,8 @@ __device__ __forceinline__ void load_pair(const L64Args& a, const TileGeom& g, c
 // arithmetic (byte formats: 11 dwords per lane stay in registers meanwhile).
 template <int HOP, class M>
 __device__ __forceinline__ void l64_body(const L64Args& a, unsigned char* lds) {
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int tid0 = threadIdx.x;
+    const int wave = tid0 >> 6, lane0 = tid0 & 63;
     const int sfmt = a.sfmt;
     const unsigned bps2 = sfmt == kSfmtS16 ? 4u : (sfmt == kSfmtF32 ? 8u : 2u);  // bytes per complex sample
     const bool bytes = bps2 == 2u;
@@ -225,24 +225,24 @@ __device__ __forceinline__ void l64_body(const L64Args& a, unsigned char* lds) {
     float* const lut = wtab + kN;
     constexpr int M6 = popc64(M::n[5]);
     constexpr int G = M6 <= 8 ? 8 : (M6 <= 16 ? 4 : (M6 <= 32 ? 2 : 1));  // windows of a wave per exchange round (host: l64_round_windows)
-    unsigned char* const zbuf = lds + a.span_bytes + 4 * kN + 1024 + static_cast<unsigned>(wave) * (static_cast<unsigned>(G) * a.zstride);
-    float* const out_mag = reinterpret_cast<float*>(lds + a.span_bytes + 4 * kN + 1024 + 4u * static_cast<unsigned>(G) * a.zstride);
+    // the exchange buffer of stages 7..9 lies over the span: by then every wave has its samples in registers (barrier below)
+    unsigned char* const zbuf = lds + static_cast<unsigned>(wave) * (static_cast<unsigned>(G) * a.zstride);
+    float* const out_mag = reinterpret_cast<float*>(lds + a.span_bytes + 4 * kN + 1024);
     float2* const out_iq = reinterpret_cast<float2*>(out_mag + a.nch * kTile);
     float2* const cplx = reinterpret_cast<float2*>(a.cplx);
 
     // ---- tables, per-lane constants of the combining step (lane -> channel is the same on every trip) ----
-    for (int i = tid; i < kN; i += 256)
+    for (int i = tid0; i < kN; i += 256)
         wtab[i] = a.window[i];
     if (bytes)
-        lut[tid] = a.levels[tid];
+        lut[tid0] = a.levels[tid0];
     const int nbp = a.nb_pad;  // channels per window, padded to a power of two (8 .. 64)
-    const int ch = lane & (nbp - 1);
+    const int ch = lane0 & (nbp - 1);
     L64Chan cc = {0, -1, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (ch < a.nch)
         cc = a.chan[ch];
     const float2 w7 = make_float2(cc.w7x, cc.w7y), w8 = make_float2(cc.w8x, cc.w8y), w9 = make_float2(cc.w9x, cc.w9y);
     const int ntrip = (G * nbp + 63) / 64;
-    const int g = lane >> 3, t = lane & 7;
 
     // A tile is "fast" when it holds byte samples, is complete, starts on a pair boundary and lies inside the capture: its raw
     // dwords are prefetched into registers a tile ahead and converted with straight-line code.  Any other tile (the last
@@ -252,10 +252,10 @@ __device__ __forceinline__ void l64_body(const L64Args& a, unsigned char* lds) {
         return bytes && q.mis == 0u && q.nw == kTile && q.byte0 + 4ll * q.npairs <= static_cast<long long>(a.valid_bytes);
     };
     auto prefetch = [&](const TileGeom& q) {
-        const unsigned* src = reinterpret_cast<const unsigned*>(q.gbase + q.byte0) + tid;
+        const unsigned* src = reinterpret_cast<const unsigned*>(q.gbase + q.byte0) + tid0;
 #pragma unroll
         for (int k = 0; k < kRawTrips; ++k)
-            pre[k] = (tid + 256u * k < q.npairs) ? src[256 * k] : 0u;
+            pre[k] = (tid0 + 256u * k < q.npairs) ? src[256 * k] : 0u;
     };
     TileGeom geo = tile_geom<HOP>(a, nx_stream, nx_tile, bps2);
     bool fast = is_fast(geo);
@@ -265,6 +265,13 @@ __device__ __forceinline__ void l64_body(const L64Args& a, unsigned char* lds) {
 
     for (unsigned tt = t_begin; tt < t_end; ++tt) {
         const int nw = geo.nw;
+        // The lane's indices, opaque to the compiler once per tile: everything derived from them (11 store addresses of the
+        // conversion, the sample addresses, the output indices) is then computed where it is used instead of being hoisted
+        // out of the tile loop into ~60 registers that stay live across the register-resident FFT.
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const int g = lane >> 3, t = lane & 7;
         // ---- raw -> float span (the previous tile's FFTs are done with it: the barrier at the end of the loop body) ----
         if (fast) {
 #pragma unroll
@@ -297,24 +304,50 @@ __device__ __forceinline__ void l64_body(const L64Args& a, unsigned char* lds) {
         }
 
         const int wi = wave * 8 + g;          // window of this lane within the tile
-        const bool wave_on = wave * 8 < nw;   // (whole-wave decision: a tail tile may have fewer than 32 windows)
+        // (a tail tile may have fewer than 32 windows: lanes and whole waves past the tail redo window 0 of the tile and drop the
+        // result -- no divergent control flow around the register-resident FFT)
         float2 v[64];
-        if (wave_on) {
+        {
             // ---- the lane's 64 samples x window coefficients into bit-reversed positions ----
-            const unsigned wclamp = wi < nw ? static_cast<unsigned>(wi) : 0u;  // lanes past the tail redo window 0 of the tile (dropped below)
+            const unsigned wclamp = wi < nw ? static_cast<unsigned>(wi) : 0u;
             const unsigned char* ls = span + span_addr<HOP>(wclamp * HOP) + 8u * t;
             const float* lw = wtab + t;
             constexpr unsigned PADB = 4u * ((16u - 2u * HOP) & 63u);
+            // Samples m and m + 32 land on the neighbouring positions rev6(m), rev6(m) + 1: stage 1 combines exactly those, so it
+            // is taken as the pair arrives and only its live outputs stay in registers (32 instead of 64 points where the plan's
+            // bins are all even or all odd).
+            constexpr int MODE1 = static_cast<int>(M::n[0] & 3ull);
 #pragma unroll
-            for (int m = 0; m < 64; ++m) {
+            for (int m = 0; m < 32; ++m) {
                 // t + 8 m never crosses a row in the middle of the eight lanes: HOP is a multiple of 8
-                // (volatile 8-byte read: one ds_read_b64 each -- merged into ds_read2_b64 they would move half the bytes per clock)
-                const unsigned long long raw = *(const lds_u64*)(ls + 64u * m + PADB * ((8u * m) / HOP));
-                const float w = lw[8 * m];
-                v[rev6(m)] = make_float2(__uint_as_float(static_cast<unsigned>(raw)) * w, __uint_as_float(static_cast<unsigned>(raw >> 32)) * w);  // :473-474
+                // (volatile 8-byte reads: one ds_read_b64 each -- merged into ds_read2_b64 they would move half the bytes per clock)
+                const unsigned long long r0 = *(const lds_u64*)(ls + 64u * m + PADB * ((8u * m) / HOP));
+                const unsigned long long r1 = *(const lds_u64*)(ls + 64u * (m + 32) + PADB * ((8u * (m + 32)) / HOP));
+                const float w0c = lw[8 * m], w1c = lw[8 * (m + 32)];
+                const float2 x0 = make_float2(__uint_as_float(static_cast<unsigned>(r0)) * w0c, __uint_as_float(static_cast<unsigned>(r0 >> 32)) * w0c);  // :473-474
+                const float2 x1 = make_float2(__uint_as_float(static_cast<unsigned>(r1)) * w1c, __uint_as_float(static_cast<unsigned>(r1 >> 32)) * w1c);
+                const int p0 = rev6(m);  // even; sample m + 32 sits at p0 + 1
+                if constexpr ((MODE1 & 1) != 0) {
+                    v[p0].x = x0.x + x1.x;
+                    v[p0].y = x0.y + x1.y;
+                }
+                if constexpr ((MODE1 & 2) != 0) {
+                    v[p0 + 1].x = x0.x - x1.x;
+                    v[p0 + 1].y = x0.y - x1.y;
+                }
+                // pin the sums here (an empty asm makes them opaque): otherwise the multiplies sink below the barrier to their first
+                // use and all 64 raw samples + coefficients stay live across it
+                if constexpr ((MODE1 & 1) != 0)
+                    asm volatile("" : "+v"(v[p0].x), "+v"(v[p0].y));
+                if constexpr ((MODE1 & 2) != 0)
+                    asm volatile("" : "+v"(v[p0 + 1].x), "+v"(v[p0 + 1].y));
+                if ((m & 7) == 7)
+                    __builtin_amdgcn_sched_barrier(0);  // eight pairs in flight at a time: the loads of the next eight stay below
             }
-            // ---- DIT stages 1..6 of the 512-point graph, in the lane ----
-            stage_from<M, 1, 0>(v);
+        }
+        __syncthreads();  // every wave has read its samples: the span may be overwritten by the exchange buffer
+        {
+            // ---- DIT stages 2..6 of the 512-point graph, in the lane (stage 1 was taken with the loads) ----
             stage_from<M, 2, 0>(v);
             stage_from<M, 3, 0>(v);
             stage_from<M, 4, 0>(v);
@@ -326,12 +359,12 @@ __device__ __forceinline__ void l64_body(const L64Args& a, unsigned char* lds) {
         //      X[bin] = ((Z0 + w7 Z4) + w8 (Z2 + w7 Z6)) + w9 ((Z1 + w7 Z5) + w8 (Z3 + w7 Z7)) ----
 #pragma unroll 1
         for (int r = 0; r < 8 / G; ++r) {
-            if (wave_on && (g / G) == r)
+            if ((g / G) == r)
                 put_classes<M, 0>(v, zbuf + static_cast<unsigned>(g % G) * a.zstride + 8u * t);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (wave_on) {
+            {
                 for (int trip = 0; trip < ntrip; ++trip) {
                     const int gl = (lane + 64 * trip) / nbp;  // window of the round
                     const int wj = wave * 8 + r * G + gl;
