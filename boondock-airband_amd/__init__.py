@@ -40,6 +40,8 @@ OPT_TP_RATIO_PCT = 8
 OPT_TP_SEG_LANES = 9
 OPT_LANE_FFT = 10
 OPT_LANE_FFT_JIT = 11
+OPT_CORE_SPLIT = 12
+OPT_SPEC_HEAD = 13
 SFMT_U8, SFMT_S8, SFMT_S16, SFMT_F32 = 1, 2, 3, 4
 
 MI_OK, MI_ERR_INVALID, MI_ERR_NO_DEVICE, MI_ERR_NOMEM, MI_ERR_HIP, MI_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
@@ -94,7 +96,7 @@ class MixInput(C.Structure):  # mi_mix_input
 ABI_SYMBOLS = [
     "mi_last_error", "mi_device_count", "mi_demod_create", "mi_demod_destroy", "mi_demod_bytes_needed", "mi_demod_bytes_consumed",
     "mi_demod_hop_bytes", "mi_demod_process", "mi_demod_submit", "mi_demod_wait", "mi_host_alloc", "mi_host_free", "mi_demod_process_device", "mi_demod_get_stats", "mi_demod_state_size",
-    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_last_stage1", "mi_demod_tp_debug", "mi_demod_kernel_time", "mi_demod_kernel_time_prev", "mi_demod_set_option", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
+    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_last_stage1", "mi_demod_tp_debug", "mi_demod_kernel_time", "mi_demod_kernel_time_prev", "mi_demod_event_ms", "mi_demod_set_option", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
     "mi_plan_window", "mi_plan_twiddles", "mi_plan_levels", "mi_plan_sincos_lut", "mi_plan_channel", "mi_plan_ctcss_coeffs",
     "mi_iqgen_host", "mi_iqgen_device", "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_is_stereo", "mi_mixer_process_device",
     "mi_gather_unique_id", "mi_gather_create", "mi_gather_destroy", "mi_gather_audio", "mi_gather_stream_wait", "mi_gather_sync",
@@ -144,6 +146,7 @@ def lib():
         L.mi_demod_last_path.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mi_demod_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.mi_demod_kernel_time_prev.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.mi_demod_event_ms.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.mi_demod_set_option.argtypes = [vp, C.c_int, C.c_int]
         L.mi_demod_tp_debug.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_int)]
         L.mi_demod_read_planes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -380,6 +383,13 @@ class Demod:
             out.append((name.value.decode(), ms.value, n.value))
             i += 1
         return out
+
+    def event_ms(self, ref_age, age, chunk, event):
+        """(diagnostic) ms from the core chain start of the call `ref_age` back to an event of the call `age` back, or None"""
+        ms = C.c_float(0)
+        if lib().mi_demod_event_ms(self._h, ref_age, age, chunk, event, C.byref(ms)) != MI_OK:
+            return None
+        return ms.value
 
     def last_kernel_ms(self):
         a, b = C.c_float(0), C.c_float(0)

@@ -152,7 +152,8 @@ struct TpArgs {
     size_t plane_stride;
     float* wmain;
     size_t wmain_stride;
-    float* carry;
+    float* carry;             // [handle rows][AGC_EXTRA] audio lookahead this call leaves (one per scratch set)
+    const float* carry_prev;  // ... and the one the previous call left: this call's first AGC_EXTRA emitted samples
     char* axc;
     const ChanParams* cp;
     ChanState* st;
@@ -166,6 +167,14 @@ struct TpArgs {
     const float* prev_mag;                     // planes of the previous call (its last TP_W1 steps warm up this call's first lanes), or null
     uint32_t prev_n;                           // steps of the previous call
     const unsigned* xmax_prev;                 // xmax of the previous call
+    // spec_head: the segment lanes whose warm-up reaches back over the start of the call (segments 0 .. TP_W / L - 1) begin it in
+    // the previous call's arrays from a guessed state, like every other lane, instead of from the carried ChanState -- the segment
+    // pass then needs nothing the previous call's tail writes, and the scan checks segment 0 against the carried state as it
+    // checks any other segment against its predecessor.
+    int spec_head;
+    const float *prev_blk_fe, *prev_blk_fm, *prev_blk_x0, *prev_blk_xm;  // [nrows][prev_nblk]
+    const TpCore* prev_core;                                              // [nrows][prev_nseg+1]
+    uint32_t prev_nblk, prev_nseg;
     int* rec;                                  // [TP_NREC][rec_stride]
     size_t rec_stride;
     int* tstart;                               // [nrows*nseg][8]
@@ -173,6 +182,7 @@ struct TpArgs {
     TpFinal* fin;                              // [nrows]
     int* diag;                                 // [nrows][4] segments not accepted in scan 0..3, then [nrows][4] core-chain block counts
     int seg_lpw;                               // lanes per wave of k_tp_seg, 0 = auto (MI_OPT_TP_SEG_LANES)
+    int core_split;                            // the noise-floor passes of the core chain on a wave of their own (k_tp_core2)
 };
 inline uint32_t tp_chunk_unit(uint32_t L) {  // lcm(L, WAVE_BATCH = 2000) for L = 2^k >= 16: 2000 = 16 * 125
     return L * 125u;

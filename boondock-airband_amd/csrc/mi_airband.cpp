@@ -101,6 +101,9 @@ struct mi_demod {
     int opt_tp_chunks = 0;    // MI_OPT_TP_CHUNKS: 0 = measured default
     double opt_tp_ratio = 0;  // MI_OPT_TP_RATIO_PCT / 100: 0 = measured default
     int opt_tp_lpw = 0;       // MI_OPT_TP_SEG_LANES: lanes per wave of the segment pass, 0 = auto
+    bool opt_spec_head = true;   // MI_OPT_SPEC_HEAD: overlapped calls start their first segments from a guessed state (see TpArgs)
+    bool opt_core_split = true;  // MI_OPT_CORE_SPLIT: noise-floor passes of the core chain on their own wave (k_tp_core2)
+    bool core_split_ok = false;  // ... the plan allows it: automatic squelch levels with a cap factor >= 1 on every channel
     bool opt_l64 = true;      // MI_OPT_LANE_FFT: the lane-resident stage 1 at N = 512 where the plan allows it
     int opt_l64_linear = 0;   // (diagnostic) tiles in blockIdx order instead of grouped per XCD
     bool opt_l64_jit = true;  // MI_OPT_LANE_FFT_JIT: compile the plan's own instance with hipRTC (else the full-graph instance)
@@ -133,7 +136,9 @@ struct mi_demod {
     mi::ChanState* d_state = nullptr;
     float* d_mag = nullptr;
     float2* d_cplx = nullptr;
-    float* d_carry = nullptr;
+    float* d_carry = nullptr;        // the audio lookahead the last call left: aliases d_carry_set[.]
+    float* d_carry_set[kSets] = {};  // time-parallel calls write the one of their scratch set (the next call's segment pass may run
+                                     // before this call's tail has applied its fades and the next call has emitted the lookahead)
     float* d_ring = nullptr;
     float* d_ctcss_coeff = nullptr;
     float* d_ctcss_q = nullptr;
@@ -223,6 +228,10 @@ void tuning_from_env(mi_demod* h) {
         const int v = std::atoi(e);
         h->opt_tp_L = (v == 512 || v == 1024 || v == 2048 || v == 4096) ? v : 0;
     }
+    if (const char* e = get("MI_AIRBAND_CORE_SPLIT"))
+        h->opt_core_split = std::atoi(e) != 0;
+    if (const char* e = get("MI_AIRBAND_SPEC_HEAD"))
+        h->opt_spec_head = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_L64"))
         h->opt_l64 = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_L64_JIT"))
@@ -445,7 +454,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.plane_stride = h->plane_stride;
         ta.wmain = d_wmain;
         ta.wmain_stride = wmain_stride;
-        ta.carry = h->d_carry;
+        ta.carry = h->d_carry_set[q];
+        ta.carry_prev = h->d_carry;
         ta.axc = d_axc;
         ta.cp = h->d_cp;
         ta.st = h->d_state;
@@ -469,6 +479,18 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.fin = h->d_fin;
         ta.diag = h->d_diag;
         ta.seg_lpw = h->opt_tp_lpw;
+        ta.core_split = (h->opt_core_split && h->core_split_ok) ? 1 : 0;
+        // Speculative head: when this call's segment pass may run under the previous call's tail at all (seg_early) and that call
+        // left what the warm-up needs (aggregates, core states at boundaries of the same segment length, TP_W steps of them),
+        // no lane starts from the carried ChanState and no launch of the pass waits for the previous call.
+        const bool spec_head = seg_early && h->opt_spec_head && h->head_off >= mi::TP_W && h->set_seq[h->cur] &&
+                               h->set_path[h->cur] == 1;
+        ta.spec_head = spec_head ? 1 : 0;
+        ta.prev_blk_fe = h->d_blk_fe[h->cur], ta.prev_blk_fm = h->d_blk_fm[h->cur];
+        ta.prev_blk_x0 = h->d_blk_x0[h->cur], ta.prev_blk_xm = h->d_blk_xm[h->cur];
+        ta.prev_core = h->d_core[h->cur];
+        ta.prev_nblk = h->head_off / 16;
+        ta.prev_nseg = h->last_nseg[h->cur];
         h->last_nseg[q] = ta.nseg;
         auto chunk = [&](int i) {
             mi::TpArgs c = ta;
@@ -509,7 +531,14 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         if (!overlap)
             HIP_TRY(hipStreamWaitEvent(fs, h->ev_entry, 0));  // stage 1 honours the caller's stream order
         else if (h->set_seq[q])
-            HIP_TRY(hipStreamWaitEvent(fs, h->ev[q][2], 0));  // the call that used this scratch set last (three back) has left it
+            HIP_TRY(hipStreamWaitEvent(fs, h->ev[q][2], 0));  // the call that used this scratch set last (kSets back) has left it
+        {
+            // ... and the call after that one has read what its speculative head needed from that set (planes, aggregates, core
+            // states): its segment pass is done (always long before; the wait costs nothing)
+            const int qn = (q + 1) % mi_demod::kSets;
+            if (h->set_seq[qn] && h->set_path[qn] == 1 && h->tp_chunks[qn] > 0)
+                HIP_TRY(hipStreamWaitEvent(fs, h->chunk_ev[qn][static_cast<size_t>(h->tp_chunks[qn] - 1) * mi_demod::kEvPerChunk + 6], 0));
+        }
         // the carried samples of the previous call (wherever they are) become the head of this call's planes
         HIP_TRY(mi::launch_move_head(planes, h->d_mag + h->head_off, h->plane_stride, h->rows, fs));
         HIP_TRY(hipMemsetAsync(h->d_xmax[q], 0, static_cast<size_t>(h->rows) * sizeof(unsigned), fs));
@@ -541,7 +570,11 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             // (events 5 -> 12 time the pass itself: they sit inside every wait of the segment stream; of a split first chunk
             // the body is timed, its few head segments are not)
             const uint32_t head_end = std::min<uint32_t>(c.seg1, mi::TP_W / L + 1);
-            if (!seg_early || c.last_chunk) {
+            if (spec_head) {
+                HIP_TRY(hipEventRecord(ev(i, 5), ss));
+                HIP_TRY(mi::launch_tp_seg(c, ss));
+                HIP_TRY(hipEventRecord(ev(i, 12), ss));
+            } else if (!seg_early || c.last_chunk) {
                 HIP_TRY(hipStreamWaitEvent(ss, h->ev_head, 0));
                 HIP_TRY(hipEventRecord(ev(i, 5), ss));
                 HIP_TRY(mi::launch_tp_seg(c, ss));
@@ -569,6 +602,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         }
         h->tp_chunks[q] = C;
         h->cur = q;
+        h->d_carry = h->d_carry_set[q];
         h->d_mag = planes;
         h->head_off = n;  // (first call: the planes hold AGC_EXTRA + n samples, the last AGC_EXTRA start at n as well)
         h->chain_live = true;
@@ -693,7 +727,7 @@ void mi_demod_destroy(mi_demod* h) {
         return;
     (void)hipSetDevice(h->gpu);
     (void)hipDeviceSynchronize();  // calls may still be in flight on the handle's own streams
-    void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_t1, h->d_prune_t2, h->d_prune_rank, h->d_l64_chan, h->d_l64_chan_full, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx_set[0], h->d_cplx_set[1], h->d_carry,
+    void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_t1, h->d_prune_t2, h->d_prune_rank, h->d_l64_chan, h->d_l64_chan_full, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx_set[0], h->d_cplx_set[1], h->d_carry_set[0], h->d_carry_set[1], h->d_carry_set[2], h->d_carry_set[3],
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats,
                     h->d_rows,   h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_fullbound, h->d_afc_spec};
     for (void* p : ptrs)
@@ -827,7 +861,8 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     h->d_mag = h->d_mag_set[0];
     TRY_OR_BAIL(dalloc(&h->d_cplx, static_cast<size_t>(nstreams) * p.n_iq_rows * h->plane_stride));
     h->d_cplx_set[0] = h->d_cplx;
-    TRY_OR_BAIL(dalloc(&h->d_carry, rows * mi::kAgcExtra));
+    TRY_OR_BAIL(dalloc(&h->d_carry_set[0], rows * mi::kAgcExtra));
+    h->d_carry = h->d_carry_set[0];
     TRY_OR_BAIL(dalloc(&h->d_ring, rows * mi::kSquelchRing));
     TRY_OR_BAIL(dalloc(&h->d_ctcss_coeff, p.ctcss_coeff.size()));
     TRY_OR_BAIL(dalloc(&h->d_ctcss_q, static_cast<size_t>(nstreams) * p.n_ctcss_rows * 4 * mi::kMaxTones));
@@ -862,6 +897,10 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     for (const mi::ChanParams& c : p.cp)
         if (c.modulation != MI_MOD_AM || c.needs_raw_iq || c.ctcss_enabled || c.notch_enabled || c.afc != 0)
             h->tp_eligible = false;
+    h->core_split_ok = h->tp_eligible;
+    for (const mi::ChanParams& c : p.cp)
+        if (c.using_manual_level || !(c.cap_factor >= 1.0f))
+            h->core_split_ok = false;  // (the chain wave's operand assumes cap >= noise floor in a burst)
     if (p.any_afc)
         TRY_OR_BAIL(dalloc(&h->d_afc_spec, static_cast<size_t>(nstreams) * p.fft_size));
     if (h->tp_eligible) {
@@ -881,6 +920,7 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
         for (int q = 1; q < mi_demod::kSets; ++q) {
             TRY_OR_BAIL(dalloc(&h->d_mag_set[q], rows * h->plane_stride));
             TRY_OR_BAIL(hipMemset(h->d_mag_set[q], 0, rows * h->plane_stride * 4));
+            TRY_OR_BAIL(dalloc(&h->d_carry_set[q], rows * mi::kAgcExtra));
         }
         for (int q = 0; q < mi_demod::kSets; ++q) {
             TRY_OR_BAIL(dalloc(&h->d_xmax[q], rows));
@@ -1408,6 +1448,22 @@ int mi_demod_kernel_time_prev(mi_demod* h, int age, int index, const char** name
     return kernel_time_of(h, age, index, name, ms_total, launches);
 }
 
+int mi_demod_event_ms(mi_demod* h, int ref_age, int age, int chunk, int event, float* ms) {
+    if (!h || !ms || age < 0 || ref_age < age || ref_age >= mi_demod::kSets || event < 0 || event >= mi_demod::kEvPerChunk || chunk < 0)
+        return fail(MI_ERR_INVALID, "bad argument");
+    const int q = (h->cur + mi_demod::kSets - age) % mi_demod::kSets, qr = (h->cur + mi_demod::kSets - ref_age) % mi_demod::kSets;
+    for (const int s : {q, qr})
+        if (!h->set_seq[s] || h->set_path[s] != 1)
+            return fail(MI_ERR_INVALID, "that call was not a time-parallel one (or its events were reused)");
+    if (h->set_seq[q] + static_cast<uint64_t>(age) != h->set_seq[h->cur] || h->set_seq[qr] + static_cast<uint64_t>(ref_age) != h->set_seq[h->cur] ||
+        chunk >= h->tp_chunks[q])
+        return fail(MI_ERR_INVALID, "no such call or chunk");
+    HIP_TRY(hipSetDevice(h->gpu));
+    HIP_TRY(hipEventSynchronize(h->ev[q][2]));
+    HIP_TRY(hipEventElapsedTime(ms, h->chunk_ev[qr][3], h->chunk_ev[q][static_cast<size_t>(chunk) * mi_demod::kEvPerChunk + event]));
+    return MI_OK;
+}
+
 int mi_demod_last_kernel_ms(mi_demod* h, float* channelize_ms, float* demod_ms) {
     if (!h || !h->set_seq[h->cur])
         return fail(MI_ERR_INVALID, "no call has been timed yet");
@@ -1468,6 +1524,12 @@ int mi_demod_set_option(mi_demod* h, int option, int value) {
             return MI_OK;
         case MI_OPT_LANE_FFT:
             h->opt_l64 = value != 0;
+            return MI_OK;
+        case MI_OPT_CORE_SPLIT:
+            h->opt_core_split = value != 0;
+            return MI_OK;
+        case MI_OPT_SPEC_HEAD:
+            h->opt_spec_head = value != 0;
             return MI_OK;
         case MI_OPT_LANE_FFT_JIT:
             h->opt_l64_jit = value != 0;

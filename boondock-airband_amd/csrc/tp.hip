@@ -260,13 +260,81 @@ __device__ __forceinline__ void ema_trial(const float (&ys)[16], const float c, 
     }
 }
 
-__global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
+// ---- the core chain on two waves (k_tp_core2) ----
+// The noise-floor passes are 0.9 ms of the 2.0 ms a 64-s call spends in the chain; the rest is loads, verification, snapshots and
+// the stepped blocks after each burst -- work that needs capped_, which only the walking wave knows.  But the passes do not need
+// it: with the operand "full_ at the block's start" the recurrence noise_floor' = 0.97 nf + 0.03 min(operand, nf) + 1e-6 gives the
+// true value in the merged regime (capped_ == full_), in a burst (both above the floor: min() is the floor) and in a decay unless
+// full_ dips under the floor before capped_ has met it.  So wave 0 of the workgroup walks nothing but those passes, 64 blocks at a
+// time, a few groups ahead, and wave 1 does everything else exactly as the one-wave kernel does, taking the per-block values
+// from a ring in LDS instead of computing them.  Every value taken is proven: a lane accepts its block only if min(true operand,
+// nf) == min(wave 0's operand, nf) bit for bit, and after blocks wave 1 advanced by itself (single blocks, decays) it compares its
+// own value with wave 0's before it takes another one.  On a disagreement wave 0 is sent back to that block with the true value
+// (~30 times per channel-minute).  Every wait is bounded; if one runs out wave 1 walks the chain itself from there (`solo`).
+constexpr unsigned kNfRing = 512;
+constexpr unsigned kOpRing = 2048;
+constexpr unsigned kShareSpin = 2u * 1000u * 1000u;
+struct CoreShare {
+    float nfring[kNfRing];  // noise floor after block b, at b % kNfRing
+    float opring[kOpRing];  // wave 0's operand of block b (full_ at its start), at b % kOpRing: fetched by wave 2
+    unsigned op_done;       // wave 2 has delivered the operands of every block below this one
+    unsigned w0_done;       // wave 0 has delivered every block below this one (since its last restart)
+    unsigned w1_pos;        // block wave 1 is at: wave 0 stays within the ring's reach of it
+    unsigned rb_seq, rb_ack, rb_blk;  // restart request of wave 1 / its acknowledgement
+    float rb_nf;            // ... the noise floor entering block rb_blk
+    unsigned quit;
+};
+// Both waves talk through LDS only, and the LDS operations of a wave execute in order: a flag written after the data is seen
+// after the data, a datum read after the flag is read after it.  So the hand-offs need no fence -- a workgroup-scope fence would
+// also wait for the wave's outstanding GLOBAL loads (the operands and blocks prefetched groups ahead), once per group -- only the
+// compiler has to keep the order.  For the same reason every access goes through an LDS-typed pointer: through a generic one a
+// volatile access is a flat_load followed by s_waitcnt vmcnt(0), which drains the prefetches just like the fence.
+typedef __attribute__((address_space(3))) CoreShare LdsShare;
+typedef __attribute__((address_space(3))) volatile unsigned lds_vu32;
+typedef __attribute__((address_space(3))) volatile float lds_vf32;
+__device__ __forceinline__ void share_order() {
+    asm volatile("" ::: "memory");
+}
+// (wave-uniform by construction; readfirstlane lets the polling loops branch on scalars)
+__device__ __forceinline__ unsigned share_peek(const __attribute__((address_space(3))) unsigned* p) {
+    return __builtin_amdgcn_readfirstlane(*(const lds_vu32*)p);
+}
+__device__ __forceinline__ void share_post(__attribute__((address_space(3))) unsigned* p, const unsigned v) {
+    *(lds_vu32*)p = v;
+}
+// wave 1: wait until wave 0 has answered the last restart request and delivered every block below `upto`
+__device__ __forceinline__ bool share_wait(LdsShare* sh, const unsigned rb_seq, const uint32_t upto) {
+    for (unsigned spin = 0;; ++spin) {
+        const unsigned ack = share_peek(&sh->rb_ack), done = share_peek(&sh->w0_done);
+        if (ack == rb_seq && done >= upto)
+            break;
+        __builtin_amdgcn_s_sleep(1);
+        if (spin > kShareSpin)
+            return false;
+    }
+    share_order();
+    return true;
+}
+// wave 1: send wave 0 back to block `blk` with the noise floor `nf` entering it
+__device__ __forceinline__ bool share_rollback(LdsShare* sh, unsigned& rb_seq, const uint32_t blk, const float nf) {
+    if (threadIdx.x == 64) {
+        share_post(&sh->rb_blk, blk);
+        *(lds_vf32*)&sh->rb_nf = nf;
+    }
+    share_order();
+    ++rb_seq;
+    if (threadIdx.x == 64)
+        share_post(&sh->rb_seq, rb_seq);
+    return share_wait(sh, rb_seq, blk);
+}
+
+template <bool kSplit>
+__device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const int lane) {
     // The chain is the critical path of a call and shares its SIMD with waves of the wide passes of other chunks: ask the
     // issue arbiter to favour it.
     __builtin_amdgcn_s_setprio(3);
     const int r = blockIdx.x;
     const int row = a.rows[r];
-    const int lane = threadIdx.x;
     const ChanParams p = a.cp[row % a.nch];
     const float* __restrict__ x = a.mag + static_cast<size_t>(row) * a.plane_stride + kAgcExtra;
     const size_t bbase = static_cast<size_t>(r) * a.nblk;
@@ -279,6 +347,13 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
     const uint32_t bps = a.L / 16;  // blocks per segment
 
     int n_run = 0, n_single = 0, n_step = 0, n_fail = 0;  // diagnostics: blocks per path, failed hypotheses
+    // kSplit: the noise-floor passes come from the chain wave (CoreShare).  `own`: this wave advanced the noise floor itself since it
+    // last took a value from there (single blocks, decays): the next value taken is only good if the chain wave agrees on the one
+    // before it.  `solo`: the chain wave was given up on (a wait ran out): from then on this wave walks the chain itself.
+    bool own = false, solo = !kSplit;
+    unsigned rb_seq = 0;
+    float fe_group = full;  // full_ at the start of the group: the chain wave's operand for the group's first block
+    int n_rollback = 0;
     CoreGroup nxt = core_load(a, x, bbase, a.blk0, lane);
     CoreGroup nxt2 = core_load(a, x, bbase, a.blk0 + 64, lane);
     for (uint32_t g0 = a.blk0; g0 < nblk; g0 += 64) {
@@ -292,6 +367,8 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
         float yv[16];
         int kk = 0;
         while (kk < nb) {
+            if (kSplit && lane == 0)
+                share_post(&sh->w1_pos, g0 + kk);
             if (c == full || c == cap) {
                 // Hypothesis: the regime of the current block persists.  The noise-floor chain is walked serially
                 // (the only true dependence), every block's precondition is then checked by its own lane.
@@ -302,7 +379,22 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                 // into the consuming operations as a DPP modifier (nf_chain_*), no lane reads or writes.
                 // After pass t lanes kk .. kk+t-1 are final; nb-kk passes settle the whole group.
                 float vnf = nf;
-                if (lane >= kk) {  // lanes below kk keep the current state; lane kk never sees a valid shifted source
+                if (kSplit && !solo) {
+                    // the chain wave has walked these blocks with min(full_ at the block's start, noise floor) as the operand
+                    if (own) {  // does it agree on the value this wave computed for the block before?
+                        const uint32_t at = g0 + kk;
+                        if (at > a.blk0 && !(share_wait(sh, rb_seq, at) && *(lds_vf32*)&sh->nfring[(at - 1u) & (kNfRing - 1u)] == nf)) {
+                            solo = !share_rollback(sh, rb_seq, at, nf) || solo;
+                            ++n_rollback;
+                        }
+                        own = false;
+                    }
+                    if (!solo && !share_wait(sh, rb_seq, g0 + nb))
+                        solo = true;
+                    if (!solo && lane >= kk)
+                        vnf = *(lds_vf32*)&sh->nfring[(g0 + lane) & (kNfRing - 1u)];
+                }
+                if (solo && lane >= kk) {  // lanes below kk keep the current state; lane kk never sees a valid shifted source
                     if (merged) {
                         const float cen = (lane == kk) ? c : fe_prev;  // capped_ (== full_) entering the lane's block
                         vnf = nf_chain_min(nf, cen, nb - kk);
@@ -324,6 +416,12 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                     ok = ok && c_entry < capj && cur.fm < capj;  // MERGED: the cap never binds inside the block
                 else
                     ok = ok && capped_step(c_entry, cur.x0, capj) == capj && cur.xm >= capj;  // SATURATED
+                if (kSplit && !solo) {
+                    // ... and the operand the chain wave used gives the same min() as the true one (it always does in the merged
+                    // regime after an exact block, and in a burst as long as full_ and the cap are above the floor)
+                    const float opw = (lane > 0) ? fe_prev : fe_group;
+                    ok = ok && __builtin_fminf(c_entry, nf_prev) == __builtin_fminf(opw, nf_prev);
+                }
                 const int nacc = min(trailing_ones_from(__ballot(ok), kk), nb - kk);
                 if (nacc > 0) {
                     if (boundary && lane >= kk && lane < kk + nacc) {
@@ -344,6 +442,7 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
                 ++n_fail;
             }
             // one block, no hypothesis
+            own = true;
             const uint32_t blk = g0 + kk;
             if (blk % bps == 0 && lane == 0) {
                 TpCore t;
@@ -460,7 +559,10 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
             }
             ++kk;
         }
+        fe_group = rl(cur.fe, 63);
     }
+    if (kSplit && lane == 0)
+        share_post(&sh->quit, 1u);
     if (lane == 0) {
         TpCore t;
         t.nf = nf, t.cap = cap, t.c = c, t.full = full;
@@ -471,8 +573,105 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
             d[0] = (a.first_chunk ? 0 : d[0]) + n_run;
             d[1] = (a.first_chunk ? 0 : d[1]) + n_single;
             d[2] = (a.first_chunk ? 0 : d[2]) + n_step;
-            d[3] = (a.first_chunk ? 0 : d[3]) + n_fail;
+            d[3] = (a.first_chunk ? 0 : d[3]) + n_fail + 100000 * n_rollback + (kSplit && solo ? 50000000 : 0);
         }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
+    core_walk<false>(a, nullptr, threadIdx.x);
+}
+
+__global__ __launch_bounds__(192) void k_tp_core2(const TpArgs a) {
+    __shared__ CoreShare sh_mem;
+    LdsShare* const sh = (LdsShare*)&sh_mem;
+    if (threadIdx.x == 0) {
+        sh->w0_done = a.blk0, sh->w1_pos = a.blk0, sh->rb_seq = 0, sh->rb_ack = 0, sh->rb_blk = a.blk0, sh->rb_nf = 0.0f, sh->quit = 0;
+        sh->op_done = a.blk0;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64 && threadIdx.x < 128) {
+        core_walk<true>(a, sh, threadIdx.x - 64);
+        return;
+    }
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const size_t bbase = static_cast<size_t>(r) * a.nblk;
+    const uint32_t nblk = a.blk1;
+    if (threadIdx.x >= 128) {
+        // ---- wave 2: the operands of wave 0, 256 blocks per trip, as far ahead of wave 1 as the ring reaches.  (Wave 0 could
+        // load them itself, but only with the loads of several groups in flight across its loop, and the compiler's wait
+        // bookkeeping turns that into a wait for the newest load at every group; a wave that does nothing else may wait.)
+        const float full0 = a.core_carry[r].full;
+        uint32_t f = a.blk0;
+        unsigned idle = 0;
+        for (;;) {
+            const unsigned quit = share_peek(&sh->quit), w1_pos = share_peek(&sh->w1_pos);
+            if (quit)
+                break;
+            if (f >= nblk || f + 256u > w1_pos + (kOpRing - 64u)) {  // done, or the ring is full (blocks behind wave 1 are free)
+                __builtin_amdgcn_s_sleep(4);
+                if (++idle > 8u * kShareSpin)
+                    break;
+                continue;
+            }
+            idle = 0;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t idx = f + 64u * i + lane;
+                const float fe = a.blk_fe[bbase + (idx > 0u ? min(idx, nblk) - 1u : 0u)];  // full_ at the start of block idx
+                v[i] = (idx == a.blk0) ? full0 : fe;  // the chunk's first block: the carried value
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *(lds_vf32*)&sh->opring[(f + 64u * i + lane) & (kOpRing - 1u)] = v[i];
+            share_order();
+            f += 256u;
+            if (lane == 0)
+                share_post(&sh->op_done, f);
+        }
+        return;
+    }
+    // ---- wave 0: the passes ----
+    __builtin_amdgcn_s_setprio(3);
+    float nf = a.core_carry[r].nf;
+    uint32_t blk = a.blk0;
+    unsigned ack = 0, idle = 0;
+    for (;;) {
+        // one round trip to LDS for the words the other waves write
+        const unsigned quit = share_peek(&sh->quit), rs = share_peek(&sh->rb_seq), w1_pos = share_peek(&sh->w1_pos), op_done = share_peek(&sh->op_done);
+        if (quit)
+            break;
+        if (rs != ack) {  // wave 1 disagrees from block rb_blk on: start again there with its noise floor
+            share_order();
+            blk = share_peek(&sh->rb_blk);
+            nf = *(lds_vf32*)&sh->rb_nf;
+            ack = rs;
+            if (lane == 0)
+                share_post(&sh->w0_done, blk);
+            share_order();
+            if (lane == 0)
+                share_post(&sh->rb_ack, ack);
+            continue;
+        }
+        const uint32_t n = min(64u, nblk - blk);
+        if (blk >= nblk || blk + 64u > w1_pos + (kNfRing - 128u) || op_done < blk + n) {  // done, far enough ahead, or no operands yet
+            __builtin_amdgcn_s_sleep(1);
+            if (++idle > 8u * kShareSpin)
+                break;  // (wave 1 never came: it gives up on its side as well)
+            continue;
+        }
+        idle = 0;
+        const float op = *(lds_vf32*)&sh->opring[(blk + lane) & (kOpRing - 1u)];
+        const float vnf = nf_chain_min(nf, op, static_cast<int>(n));
+        if (lane < static_cast<int>(n))
+            *(lds_vf32*)&sh->nfring[(blk + lane) & (kNfRing - 1u)] = vnf;
+        share_order();
+        if (lane == 0)
+            share_post(&sh->w0_done, blk + n);
+        nf = rl(vnf, static_cast<int>(n) - 1);
+        blk += n;
     }
 }
 
@@ -1096,7 +1295,8 @@ __global__ __launch_bounds__(64) void k_tp_seg(const TpArgs a) {
     const uint32_t wk = k > wsegs ? k - wsegs : 0;  // boundary index where the warm-up starts
     TpLane s;
     seg_reset(s);
-    if (wk == 0) {  // from the true state at the start of the call
+    const bool spec = a.spec_head != 0;
+    if (wk == 0 && !spec) {  // from the true state at the start of the call
         const ChanState& cs = a.st[row];
         s.cur = cs.current_state, s.next = cs.next_state, s.delay = cs.delay, s.low = cs.low_signal_count;
         s.recent = static_cast<int>(cs.recent_open_count), s.closed = static_cast<int>(cs.closed_sample_count);
@@ -1107,8 +1307,33 @@ __global__ __launch_bounds__(64) void k_tp_seg(const TpArgs a) {
         s.closed = kRecent;
         s.agc = 0.5f;
     }
-    load_core(s, p, a.core[static_cast<size_t>(r) * (a.nseg + 1) + wk]);
-    tp_run<false>(s, p, a, r, row, magrow, wk * a.L, s0, 0, static_cast<size_t>(r) * a.nseg + k);
+    const size_t rec_idx = static_cast<size_t>(r) * a.nseg + k;
+    // The warm-up is one run over this call's arrays, preceded -- when it reaches back over the start of the call and the head is
+    // speculative -- by one over the previous call's (phase 0).  One copy of the block code serves both: the arrays are switched.
+    TpArgs aw = a;
+    const float* __restrict__ mrow = magrow;
+    uint32_t w0 = wk * a.L, w1 = s0;
+    int ph = 1;
+    if (spec && k < wsegs) {
+        const uint32_t wkp = (a.prev_n - (TP_W - k * a.L)) / a.L;  // the last boundary of the previous call that leaves TP_W steps
+        load_core(s, p, a.prev_core[static_cast<size_t>(r) * (a.prev_nseg + 1) + wkp]);
+        aw.blk_fe = const_cast<float*>(a.prev_blk_fe), aw.blk_fm = const_cast<float*>(a.prev_blk_fm);
+        aw.blk_x0 = const_cast<float*>(a.prev_blk_x0), aw.blk_xm = const_cast<float*>(a.prev_blk_xm);
+        aw.nblk = a.prev_nblk;
+        mrow = a.prev_mag + static_cast<size_t>(row) * a.plane_stride;
+        w0 = wkp * a.L, w1 = a.prev_n;
+        ph = 0;
+    } else {
+        load_core(s, p, a.core[static_cast<size_t>(r) * (a.nseg + 1) + wk]);
+    }
+#pragma unroll 1
+    for (; ph < 2; ++ph) {
+        tp_run<false>(s, p, aw, r, row, mrow, w0, w1, 0, rec_idx);
+        aw.blk_fe = a.blk_fe, aw.blk_fm = a.blk_fm, aw.blk_x0 = a.blk_x0, aw.blk_xm = a.blk_xm;
+        aw.nblk = a.nblk;
+        mrow = magrow;
+        w0 = 0, w1 = s0;  // (only reached after phase 0: the rest of the warm-up, from the start of this call)
+    }
     const TpFsm S = canon(s);
     const float s_agc = s.agc;
     seg_reset(s);
@@ -1505,7 +1730,7 @@ __global__ void k_tp_audio_head(const TpArgs a) {
         return;
     const int r = gid / kAgcExtra, v = gid - r * kAgcExtra;
     const int row = a.rows[r];
-    a.wmain[static_cast<size_t>(row) * a.wmain_stride + v] = a.carry[static_cast<size_t>(row) * kAgcExtra + v];
+    a.wmain[static_cast<size_t>(row) * a.wmain_stride + v] = a.carry_prev[static_cast<size_t>(row) * kAgcExtra + v];
 }
 
 }  // namespace
@@ -1544,7 +1769,10 @@ hipError_t launch_tp_audio_head(const TpArgs& a, hipStream_t s) {
 hipError_t launch_tp_core(const TpArgs& a, hipStream_t s) {
     if (a.nrows == 0 || a.step1 <= a.step0)
         return hipSuccess;
-    TP_LAUNCH(k_tp_core, a.nrows, 64);
+    if (a.core_split)
+        TP_LAUNCH(k_tp_core2, a.nrows, 192);
+    else
+        TP_LAUNCH(k_tp_core, a.nrows, 64);
     return hipSuccess;
 }
 

@@ -199,6 +199,11 @@ int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms_to
  * not been reused; serial calls reuse the set of the call before them).  Lets a caller that keeps calls in flight read the
  * timings of call k after it has enqueued calls k+1, k+2, without draining the pipeline. */
 int mi_demod_kernel_time_prev(mi_demod* h, int age, int index, const char** name, float* ms_total, int* launches);
+/* (diagnostic) Where a launch of a time-parallel call sat in time: milliseconds from the start of the core chain of the call
+ * `ref_age` calls back to event `event` of chunk `chunk` of the call `age` calls back (events per chunk: 0 / 1 stage 1 begin / end,
+ * 11 / 2 k_tp_full begin / end, 3 / 4 core chain begin / end, 5 / 12 segment pass begin / end, 10 / 7 scan begin / end, 8 fix end,
+ * 9 finish end).  tools/call_timeline.py prints the table. */
+int mi_demod_event_ms(mi_demod* h, int ref_age, int age, int chunk, int event, float* ms);
 
 /* Options.  MI_OPT_EARLY_INPUT (default 0): the caller guarantees that the IQ bytes handed to
  * mi_demod_process_device() are valid when the call is made (not merely in the order of `hip_stream`), e.g. a capture
@@ -215,7 +220,7 @@ enum {
     MI_OPT_EARLY_INPUT = 1,
     MI_OPT_STEADY_BLOCKS = 2,
     /* Tuning switches, all result-neutral (every combination is bit-identical; they exist for measurements and tests).
-     * A handle takes its defaults from the caller's environment when it is created (MI_AIRBAND_TP, _PRUNE, _L64, _L64_JIT, _CONV=lut|arith,
+     * A handle takes its defaults from the caller's environment when it is created (MI_AIRBAND_TP, _PRUNE, _L64, _L64_JIT, _CORE_SPLIT, _CONV=lut|arith,
      * _STEADY, _UNI_ROWS, _TP_CHUNKS, _TP_RATIO, _TP_LPW); the library itself keeps no process-wide state. */
     MI_OPT_TIME_PARALLEL = 3, /* -1 auto (plain AM plans, calls of >= 8 batches), 0 serial kernel, 1 whenever eligible */
     MI_OPT_PRUNE_FFT = 4,     /* 1 (default): at N = 512 evaluate only the FFT nodes the picked bins need */
@@ -225,6 +230,11 @@ enum {
     MI_OPT_TP_RATIO_PCT = 8,  /* growth of consecutive chunks in percent (150 = 1.5x), 0 = default */
     MI_OPT_TP_SEG_LANES = 9,  /* lanes per wave of the segment pass, 0 = auto */
     MI_OPT_LANE_FFT = 10,     /* 1 (default): at N = 512 the first six FFT stages stay in the lanes (l64_kernel.h) where the plan allows */
+    MI_OPT_CORE_SPLIT = 12,   /* 1 (default): the exact squelch core chain of the time-parallel path runs on three waves per channel -- one walks
+                               * the noise-floor recurrence, one verifies, snapshots and steps, one fetches (tp.hip, k_tp_core2); 0: one wave */
+    MI_OPT_SPEC_HEAD = 13,    /* 1 (default): when consecutive calls overlap (MI_OPT_EARLY_INPUT, alternating audio buffers) the first segments
+                               * of a call warm up on the previous call's samples from a guessed state, as all others do, instead of waiting
+                               * for the state that call's tail leaves; the scan checks them against it afterwards */
     MI_OPT_LANE_FFT_JIT = 11  /* 1 (default): that kernel is compiled for the plan's own FFT nodes by hipRTC on first use (the code object is
                                * cached per (device, hop, masks) for the life of the process); 0, or hipRTC missing: the prebuilt full graph */
 };
