@@ -182,6 +182,7 @@ struct TpArgs {
     TpFinal* fin;                              // [nrows]
     int* diag;                                 // [nrows][4] segments not accepted in scan 0..3, then [nrows][4] core-chain block counts
     int seg_lpw;                               // lanes per wave of k_tp_seg, 0 = auto (MI_OPT_TP_SEG_LANES)
+    int core_lead;                             // ... how many blocks its noise-floor wave may run ahead (0 = default)
     int core_split;                            // the noise-floor passes of the core chain on a wave of their own (k_tp_core2)
 };
 inline uint32_t tp_chunk_unit(uint32_t L) {  // lcm(L, WAVE_BATCH = 2000) for L = 2^k >= 16: 2000 = 16 * 125

@@ -102,6 +102,7 @@ struct mi_demod {
     double opt_tp_ratio = 0;  // MI_OPT_TP_RATIO_PCT / 100: 0 = measured default
     int opt_tp_lpw = 0;       // MI_OPT_TP_SEG_LANES: lanes per wave of the segment pass, 0 = auto
     bool opt_spec_head = true;   // MI_OPT_SPEC_HEAD: overlapped calls start their first segments from a guessed state (see TpArgs)
+    int opt_core_lead = 0;       // (diagnostic, MI_AIRBAND_CORE_LEAD) blocks the noise-floor wave may run ahead, 0 = default
     bool opt_core_split = true;  // MI_OPT_CORE_SPLIT: noise-floor passes of the core chain on their own wave (k_tp_core2)
     bool core_split_ok = false;  // ... the plan allows it: automatic squelch levels with a cap factor >= 1 on every channel
     bool opt_l64 = true;      // MI_OPT_LANE_FFT: the lane-resident stage 1 at N = 512 where the plan allows it
@@ -230,6 +231,8 @@ void tuning_from_env(mi_demod* h) {
     }
     if (const char* e = get("MI_AIRBAND_CORE_SPLIT"))
         h->opt_core_split = std::atoi(e) != 0;
+    if (const char* e = get("MI_AIRBAND_CORE_LEAD"))
+        h->opt_core_lead = std::max(0, std::atoi(e));
     if (const char* e = get("MI_AIRBAND_SPEC_HEAD"))
         h->opt_spec_head = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_L64"))
@@ -480,6 +483,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.diag = h->d_diag;
         ta.seg_lpw = h->opt_tp_lpw;
         ta.core_split = (h->opt_core_split && h->core_split_ok) ? 1 : 0;
+        ta.core_lead = h->opt_core_lead;
         // Speculative head: when this call's segment pass may run under the previous call's tail at all (seg_early) and that call
         // left what the warm-up needs (aggregates, core states at boundaries of the same segment length, TP_W steps of them),
         // no lane starts from the carried ChanState and no launch of the pass waits for the previous call.

@@ -152,6 +152,9 @@ __global__ __launch_bounds__(64) void k_tp_full(const TpArgs a) {
 __device__ __forceinline__ float rl(const float v, const int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+__device__ __forceinline__ float uni(const float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
 // lane j <- lane j-1, lane 0 <- `first` (DPP wave_shr:1, all lanes take part: call it from uniform control flow only)
 __device__ __forceinline__ float wave_shr1(const float v, const float first) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xf, 0xf, false));
@@ -196,6 +199,14 @@ __device__ __forceinline__ float nf_chain_min(const float nf, const float operan
         asm volatile(NF_X4(NF_X4(NF_PASS_MIN)) : "+v"(v), "+v"(m), "+v"(a), "=&v"(b) : "v"(operand), "v"(k97), "v"(k03));
     for (; t < passes; t += 4)
         asm volatile(NF_X4(NF_PASS_MIN) : "+v"(v), "+v"(m), "+v"(a), "=&v"(b) : "v"(operand), "v"(k97), "v"(k03));
+    return v;
+}
+// ... a full group in one piece: no loop, no branch
+__device__ __forceinline__ float nf_chain_min64(const float nf, const float operand) {
+    const float k97 = 0.97f, k03 = static_cast<float>(1.0 - static_cast<double>(0.97f));
+    float v = nf, m, a = nf * k97, b;
+    asm volatile("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(operand), "v"(nf));
+    asm volatile(NF_X4(NF_X4(NF_X4(NF_PASS_MIN))) : "+v"(v), "+v"(m), "+v"(a), "=&v"(b) : "v"(operand), "v"(k97), "v"(k03));
     return v;
 }
 // operand_j = the chain value itself (capped_ == cap >= noise floor): min() is the identity
@@ -271,8 +282,8 @@ __device__ __forceinline__ void ema_trial(const float (&ys)[16], const float c, 
 // nf) == min(wave 0's operand, nf) bit for bit, and after blocks wave 1 advanced by itself (single blocks, decays) it compares its
 // own value with wave 0's before it takes another one.  On a disagreement wave 0 is sent back to that block with the true value
 // (~30 times per channel-minute).  Every wait is bounded; if one runs out wave 1 walks the chain itself from there (`solo`).
-constexpr unsigned kNfRing = 512;
-constexpr unsigned kOpRing = 2048;
+constexpr unsigned kNfRing = 2048;
+constexpr unsigned kOpRing = 4096;
 constexpr unsigned kShareSpin = 2u * 1000u * 1000u;
 struct CoreShare {
     float nfring[kNfRing];  // noise floor after block b, at b % kNfRing
@@ -303,7 +314,9 @@ __device__ __forceinline__ void share_post(__attribute__((address_space(3))) uns
     *(lds_vu32*)p = v;
 }
 // wave 1: wait until wave 0 has answered the last restart request and delivered every block below `upto`
-__device__ __forceinline__ bool share_wait(LdsShare* sh, const unsigned rb_seq, const uint32_t upto) {
+__device__ __forceinline__ bool share_wait(LdsShare* sh, const unsigned rb_seq_in, const uint32_t upto_in) {
+    // (both wave-uniform; saying so keeps the polling loop on scalar branches)
+    const unsigned rb_seq = __builtin_amdgcn_readfirstlane(rb_seq_in), upto = __builtin_amdgcn_readfirstlane(upto_in);
     for (unsigned spin = 0;; ++spin) {
         const unsigned ack = share_peek(&sh->rb_ack), done = share_peek(&sh->w0_done);
         if (ack == rb_seq && done >= upto)
@@ -344,7 +357,8 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
     // the chain state comes from the previous chunk's core kernel (k_tp_prologue seeds it from the carried ChanState)
     float nf = a.core_carry[r].nf, cap = a.core_carry[r].cap, c = a.core_carry[r].c, full = a.core_carry[r].full;
     const uint32_t nblk = a.blk1;
-    const uint32_t bps = a.L / 16;  // blocks per segment
+    const uint32_t bps = a.L / 16;  // blocks per segment (a power of two: TP_L_MIN .. TP_L_MAX)
+    const uint32_t bps_log = 31u - static_cast<uint32_t>(__builtin_clz(bps));
 
     int n_run = 0, n_single = 0, n_step = 0, n_fail = 0;  // diagnostics: blocks per path, failed hypotheses
     // kSplit: the noise-floor passes come from the chain wave (CoreShare).  `own`: this wave advanced the noise floor itself since it
@@ -362,11 +376,13 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
         nxt2 = core_load(a, x, bbase, g0 + 128, lane);  // two groups in flight while this one is walked (past the end: the last block again)
         const int nb = static_cast<int>(min(64u, nblk - g0));
         const float fe_prev = wave_shr1(cur.fe, 0.0f);  // full_ at the start of lane's block, valid for lane > kk
-        const bool boundary = ((g0 + lane) % bps) == 0;
+        const bool boundary = ((g0 + lane) & (bps - 1u)) == 0;  // (bps is a power of two)
         bool ys_ready = false;
         float yv[16];
         int kk = 0;
         while (kk < nb) {
+            // (wave-uniform by construction; saying so lets the branches below be scalar ones)
+            nf = uni(nf), cap = uni(cap), c = uni(c), full = uni(full);
             if (kSplit && lane == 0)
                 share_post(&sh->w1_pos, g0 + kk);
             if (c == full || c == cap) {
@@ -383,7 +399,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                     // the chain wave has walked these blocks with min(full_ at the block's start, noise floor) as the operand
                     if (own) {  // does it agree on the value this wave computed for the block before?
                         const uint32_t at = g0 + kk;
-                        if (at > a.blk0 && !(share_wait(sh, rb_seq, at) && *(lds_vf32*)&sh->nfring[(at - 1u) & (kNfRing - 1u)] == nf)) {
+                        if (at > a.blk0 && !(share_wait(sh, rb_seq, at) && uni(*(lds_vf32*)&sh->nfring[(at - 1u) & (kNfRing - 1u)]) == nf)) {
                             solo = !share_rollback(sh, rb_seq, at, nf) || solo;
                             ++n_rollback;
                         }
@@ -427,7 +443,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                     if (boundary && lane >= kk && lane < kk + nacc) {
                         TpCore t;
                         t.nf = nf_prev, t.cap = cap_prev, t.c = c_entry, t.full = full_entry;
-                        core[(g0 + lane) / bps] = t;
+                        core[(g0 + lane) >> bps_log] = t;
                     }
                     const int last = kk + nacc - 1;
                     nf = rl(vnf, last);
@@ -444,10 +460,10 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
             // one block, no hypothesis
             own = true;
             const uint32_t blk = g0 + kk;
-            if (blk % bps == 0 && lane == 0) {
+            if ((blk & (bps - 1u)) == 0 && lane == 0) {
                 TpCore t;
                 t.nf = nf, t.cap = cap, t.c = c, t.full = full;
-                core[blk / bps] = t;
+                core[blk >> bps_log] = t;
             }
             float fe = rl(cur.fe, kk);
             const float fm = rl(cur.fm, kk), x0 = rl(cur.x0, kk), xm = rl(cur.xm, kk);
@@ -520,7 +536,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                             if (boundary && lane > kk && lane <= kk + nacc) {
                                 TpCore t;  // the state at the start of the lane's block
                                 t.nf = nf_in, t.cap = cap_in, t.c = c_in, t.full = fe_prev;
-                                core[(g0 + lane) / bps] = t;
+                                core[(g0 + lane) >> bps_log] = t;
                             }
                             kk += nacc;
                             nf = rl(nfL, kk);
@@ -634,37 +650,45 @@ __global__ __launch_bounds__(192) void k_tp_core2(const TpArgs a) {
         return;
     }
     // ---- wave 0: the passes ----
+    // A group is 64 x 6 issue slots of passes; everything else in the loop is kept off its path: the words the other waves write
+    // are read a group ahead (stale by one group, which only makes the decisions below later or more cautious), the straight
+    // path has one taken branch, and a full group runs its 64 passes as one block of code.
     __builtin_amdgcn_s_setprio(3);
     float nf = a.core_carry[r].nf;
     uint32_t blk = a.blk0;
     unsigned ack = 0, idle = 0;
+    const uint32_t lead = min(static_cast<uint32_t>(a.core_lead > 0 ? a.core_lead : 768), kNfRing - 128u);  // blocks wave 0 may be ahead of wave 1
+    unsigned quit = share_peek(&sh->quit), rs = share_peek(&sh->rb_seq), w1_pos = share_peek(&sh->w1_pos), op_done = share_peek(&sh->op_done);
     for (;;) {
-        // one round trip to LDS for the words the other waves write
-        const unsigned quit = share_peek(&sh->quit), rs = share_peek(&sh->rb_seq), w1_pos = share_peek(&sh->w1_pos), op_done = share_peek(&sh->op_done);
-        if (quit)
-            break;
-        if (rs != ack) {  // wave 1 disagrees from block rb_blk on: start again there with its noise floor
-            share_order();
-            blk = share_peek(&sh->rb_blk);
-            nf = *(lds_vf32*)&sh->rb_nf;
-            ack = rs;
-            if (lane == 0)
-                share_post(&sh->w0_done, blk);
-            share_order();
-            if (lane == 0)
-                share_post(&sh->rb_ack, ack);
-            continue;
-        }
         const uint32_t n = min(64u, nblk - blk);
-        if (blk >= nblk || blk + 64u > w1_pos + (kNfRing - 128u) || op_done < blk + n) {  // done, far enough ahead, or no operands yet
-            __builtin_amdgcn_s_sleep(1);
-            if (++idle > 8u * kShareSpin)
-                break;  // (wave 1 never came: it gives up on its side as well)
+        const bool go = !quit && rs == ack && blk < nblk && blk + 64u <= w1_pos + lead && op_done >= blk + n;
+        if (__builtin_expect(!go, 0)) {
+            if (quit)
+                break;
+            if (rs != ack) {  // wave 1 disagrees from block rb_blk on: start again there with its noise floor
+                share_order();
+                blk = share_peek(&sh->rb_blk);
+                nf = *(lds_vf32*)&sh->rb_nf;
+                ack = rs;
+                if (lane == 0)
+                    share_post(&sh->w0_done, blk);
+                share_order();
+                if (lane == 0)
+                    share_post(&sh->rb_ack, ack);
+            } else {  // done, far enough ahead, or no operands yet
+                __builtin_amdgcn_s_sleep(1);
+                if (++idle > 8u * kShareSpin)
+                    break;  // (wave 1 never came: it gives up on its side as well)
+            }
+            quit = share_peek(&sh->quit), rs = share_peek(&sh->rb_seq), w1_pos = share_peek(&sh->w1_pos), op_done = share_peek(&sh->op_done);
             continue;
         }
         idle = 0;
         const float op = *(lds_vf32*)&sh->opring[(blk + lane) & (kOpRing - 1u)];
-        const float vnf = nf_chain_min(nf, op, static_cast<int>(n));
+        // (the next trip's view of the other waves: in flight during the passes)
+        const unsigned quit_n = *(const lds_vu32*)&sh->quit, rs_n = *(const lds_vu32*)&sh->rb_seq, w1_n = *(const lds_vu32*)&sh->w1_pos,
+                       opd_n = *(const lds_vu32*)&sh->op_done;
+        const float vnf = (n == 64u) ? nf_chain_min64(nf, op) : nf_chain_min(nf, op, static_cast<int>(n));
         if (lane < static_cast<int>(n))
             *(lds_vf32*)&sh->nfring[(blk + lane) & (kNfRing - 1u)] = vnf;
         share_order();
@@ -672,6 +696,8 @@ __global__ __launch_bounds__(192) void k_tp_core2(const TpArgs a) {
             share_post(&sh->w0_done, blk + n);
         nf = rl(vnf, static_cast<int>(n) - 1);
         blk += n;
+        quit = __builtin_amdgcn_readfirstlane(quit_n), rs = __builtin_amdgcn_readfirstlane(rs_n);
+        w1_pos = __builtin_amdgcn_readfirstlane(w1_n), op_done = __builtin_amdgcn_readfirstlane(opd_n);
     }
 }
 
