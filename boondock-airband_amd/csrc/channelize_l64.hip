@@ -71,12 +71,14 @@ hipError_t launch_channelize_l64(const ChannelizeArgs& c, int sfmt, int nstreams
     a.sfmt = sfmt;
     a.linear_tiles = c.l64.linear_tiles;
     // (the exchange buffer of stages 7..9, 4 waves x round windows x zstride, lies over the span)
-    const size_t lds = static_cast<size_t>(a.span_bytes) + 4 * mi_l64::kN + 1024 + static_cast<size_t>(c.nch) * mi_l64::kTile * 4 +
+    const size_t lds = static_cast<size_t>(a.span_bytes) + 4 * mi_l64::kN + 1024 + 16 + static_cast<size_t>(c.nch) * mi_l64::kTile * 4 +
                        static_cast<size_t>(c.n_iq_rows) * mi_l64::kTile * 8;
     if (lds > 160 * 1024 || 4u * static_cast<size_t>(l64_round_windows(m6)) * a.zstride > a.span_bytes || static_cast<unsigned long long>(a.ntiles) * static_cast<unsigned>(nstreams) >= (1ull << 32))
         return hipErrorInvalidValue;
     a.nstreams = static_cast<unsigned>(nstreams);
-    // persistent workgroups, each walking a contiguous run of tiles: two per CU are resident (LDS), a few more keep the tail short
+    // persistent workgroups that draw runs of contiguous tiles from a ticket counter (l64_kernel.h): as many as the machine
+    // holds at once when this launch has it to itself -- fewer are resident when other kernels of the pipeline run alongside,
+    // the rest then find the tickets gone
     const unsigned long long ttotal = static_cast<unsigned long long>(a.ntiles) * a.nstreams;
     static const int cus = [] {  // (a property of the machine, asked once)
         int dev = 0, n = 256;
@@ -88,7 +90,21 @@ hipError_t launch_channelize_l64(const ChannelizeArgs& c, int sfmt, int nstreams
     // allows it, else 2): a remainder would queue behind the resident ones and leave CUs idle at the end
     const int resident = (jit && l64_jit_minwaves(jit) >= 3 && lds * 3 <= 160 * 1024) ? 3 : 2;
     const unsigned long long want = static_cast<unsigned long long>(cus) * (c.l64.wg_per_cu > 0 ? c.l64.wg_per_cu : 2 * resident);
-    const unsigned gx = static_cast<unsigned>(ttotal < want ? ttotal : want);
+    // runs of up to 8 tiles (output cache lines shared by neighbouring tiles stay in one workgroup), shorter when the launch is
+    // small: at least ~8 runs per workgroup, so that the last ones to finish are not far behind
+    if (!c.l64_tickets || !c.l64_ticket_seq)
+        return hipErrorInvalidValue;
+    unsigned run = static_cast<unsigned>(ttotal / (want * 8ull));
+    run = run < 1u ? 1u : (run > 8u ? 8u : run);
+    a.run_tiles = run;
+    const unsigned long long nruns = (ttotal + run - 1) / run;
+    const unsigned gx = static_cast<unsigned>(nruns < want ? nruns : want);
+    a.ticket = c.l64_tickets + (*c.l64_ticket_seq)++ % kL64Tickets;
+    {
+        hipError_t e = hipMemsetAsync(a.ticket, 0, sizeof(unsigned), s);
+        if (e != hipSuccess)
+            return e;
+    }
     if (jit)
         return l64_jit_launch(jit, a, gx, 1u, lds, s);
     auto kern = hop == 160 ? k_channelize_l64<160> : k_channelize_l64<128>;

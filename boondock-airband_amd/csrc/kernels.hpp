@@ -43,6 +43,7 @@ struct ChanState {
     float lp_xr[3], lp_xi[3], lp_yr[3], lp_yi[3];
 };
 
+constexpr unsigned kL64Tickets = 32;  // launches of the lane-resident stage 1 that may be in flight at once, generously
 struct ChannelizeArgs {
     const unsigned char* iq;  // stream s at iq + s*stream_stride
     size_t stream_stride;
@@ -69,6 +70,8 @@ struct ChannelizeArgs {
     const L64Chan* l64_chan;       // [nch] for the plan's own instance
     const L64Chan* l64_chan_full;  // [nch] for the full-graph instance
     const struct L64Jit* l64_jit;  // the plan's own instance (l64_jit.cpp), or null: the full-graph instance runs
+    unsigned* l64_tickets;         // [kL64Tickets] device counters, one per launch in turn (zeroed on the launch stream)
+    unsigned* l64_ticket_seq;      // host: launches so far
     const ChanState* st;  // AFC handles: the bin of (stream, channel) is st[..].afc_bin; null: ChanParams::bin
     float* afc_spec;      // AFC handles: [nstreams][fft_size] re^2+im^2 of the LAST window of the launch (AFC::square), or null
 };

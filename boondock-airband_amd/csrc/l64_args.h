@@ -32,6 +32,8 @@ struct L64Args {
     unsigned nstreams;
     int sfmt;                           // MI_SFMT_*
     int linear_tiles;                   // (unused)
+    unsigned* ticket;                   // zero before the launch: runs of tiles are handed out through it
+    unsigned run_tiles;                 // tiles per run
 };
 
 #endif

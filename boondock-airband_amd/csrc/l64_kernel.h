@@ -199,9 +199,12 @@ __device__ __forceinline__ void load_pair(const L64Args& a, const TileGeom& g, c
     }
 }
 
-// A workgroup walks a contiguous run of the launch's tiles (tile id = stream * ntiles + tile): consecutive tiles of a stream
-// overlap in the capture and share cache lines in the output rows, which then meet in one CU's L1 / one XCD's L2.  The raw
-// bytes of tile k+1 are requested before the FFTs of tile k start and converted after them: HBM latency hides under the
+// A workgroup walks runs of `run_tiles` contiguous tiles of the launch (tile id = stream * ntiles + tile): consecutive tiles of a
+// stream overlap in the capture and share cache lines in the output rows, which then meet in one CU's L1 / one XCD's L2.  The
+// first run of a workgroup is its blockIdx, every further one is drawn from a ticket counter -- not a fixed share per
+// workgroup: other kernels of the pipeline run alongside (segment passes, the core chains) and take LDS and wave slots, so only
+// part of the grid is resident at a time, and with fixed shares the launch lasted as long as the workgroups that started last.
+// The raw bytes of tile k+1 are requested before the FFTs of tile k start and converted after them: HBM latency hides under the
 // arithmetic (byte formats: 11 dwords per lane stay in registers meanwhile).
 template <int HOP, class M>
 __device__ __forceinline__ void l64_body(const L64Args& a, unsigned char* lds) {
@@ -211,13 +214,14 @@ __device__ __forceinline__ void l64_body(const L64Args& a, unsigned char* lds) {
     const unsigned bps2 = sfmt == kSfmtS16 ? 4u : (sfmt == kSfmtF32 ? 8u : 2u);  // bytes per complex sample
     const bool bytes = bps2 == 2u;
 
-    // this workgroup's run of tiles [t_begin, t_end) of the launch's nstreams * ntiles (the host keeps that below 2^32)
+    // this workgroup's first run of tiles [t_begin, t_end) of the launch's nstreams * ntiles (the host keeps that below 2^32)
     const unsigned ttotal = a.ntiles * a.nstreams;
-    const unsigned t_begin = static_cast<unsigned>(static_cast<unsigned long long>(ttotal) * blockIdx.x / gridDim.x);
-    const unsigned t_end = static_cast<unsigned>(static_cast<unsigned long long>(ttotal) * (blockIdx.x + 1u) / gridDim.x);
-    if (t_begin >= t_end)
+    const unsigned nruns = (ttotal + a.run_tiles - 1u) / a.run_tiles;
+    if (blockIdx.x >= nruns)
         return;
-    int nx_stream = static_cast<int>(t_begin / a.ntiles);          // (one division per workgroup)
+    unsigned t_begin = blockIdx.x * a.run_tiles;
+    unsigned t_end = min(t_begin + a.run_tiles, ttotal);
+    int nx_stream = static_cast<int>(t_begin / a.ntiles);          // (one division per run)
     unsigned nx_tile = t_begin - static_cast<unsigned>(nx_stream) * a.ntiles;
 
     unsigned char* const span = lds;
@@ -227,7 +231,7 @@ __device__ __forceinline__ void l64_body(const L64Args& a, unsigned char* lds) {
     constexpr int G = M6 <= 8 ? 8 : (M6 <= 16 ? 4 : (M6 <= 32 ? 2 : 1));  // windows of a wave per exchange round (host: l64_round_windows)
     // the exchange buffer of stages 7..9 lies over the span: by then every wave has its samples in registers (barrier below)
     unsigned char* const zbuf = lds + static_cast<unsigned>(wave) * (static_cast<unsigned>(G) * a.zstride);
-    float* const out_mag = reinterpret_cast<float*>(lds + a.span_bytes + 4 * kN + 1024);
+    float* const out_mag = reinterpret_cast<float*>(lds + a.span_bytes + 4 * kN + 1024 + 16);
     float2* const out_iq = reinterpret_cast<float2*>(out_mag + a.nch * kTile);
     float2* const cplx = reinterpret_cast<float2*>(a.cplx);
 
@@ -263,8 +267,12 @@ __device__ __forceinline__ void l64_body(const L64Args& a, unsigned char* lds) {
         prefetch(geo);
     __syncthreads();  // tables
 
+    unsigned* const next_run = reinterpret_cast<unsigned*>(lut + 256);  // (16 bytes between the level table and the output rows)
     for (unsigned tt = t_begin; tt < t_end; ++tt) {
         const int nw = geo.nw;
+        // the last tile of a run: draw the next one (the answer is read after the barrier below)
+        if (tt + 1 == t_end && tid0 == 0)
+            *next_run = gridDim.x + atomicAdd(a.ticket, 1u);
         // The lane's indices, opaque to the compiler once per tile: everything derived from them (11 store addresses of the
         // conversion, the sample addresses, the output indices) is then computed where it is used instead of being hoisted
         // out of the tile loop into ~60 registers that stay live across the register-resident FFT.
@@ -294,9 +302,22 @@ __device__ __forceinline__ void l64_body(const L64Args& a, unsigned char* lds) {
         __syncthreads();
         // ---- request the next tile's bytes: they arrive while this tile's FFTs run ----
         const TileGeom cur = geo;
-        if (tt + 1 < t_end) {
+        bool more = tt + 1 < t_end;
+        if (more) {
             if (++nx_tile == a.ntiles)
                 nx_tile = 0, ++nx_stream;
+        } else {
+            const unsigned run = *reinterpret_cast<volatile unsigned*>(next_run);
+            if (run < nruns) {  // the next run (one division per run)
+                const unsigned nb = run * a.run_tiles;
+                t_end = min(nb + a.run_tiles, ttotal);
+                nx_stream = static_cast<int>(nb / a.ntiles);
+                nx_tile = nb - static_cast<unsigned>(nx_stream) * a.ntiles;
+                tt = nb - 1u;  // (the loop's increment makes it nb)
+                more = true;
+            }
+        }
+        if (more) {
             geo = tile_geom<HOP>(a, nx_stream, nx_tile, bps2);
             fast = is_fast(geo);
             if (fast)

@@ -127,6 +127,8 @@ struct mi_demod {
     int* d_prune_rank = nullptr;
     L64Chan* d_l64_chan = nullptr;       // per-channel tables of the lane-resident stage 1 (plan.l64): the plan's own instance,
     L64Chan* d_l64_chan_full = nullptr;  // the full-graph instance
+    unsigned* d_l64_tickets = nullptr;   // run counters of its launches (kernels.hpp, kL64Tickets)
+    unsigned l64_ticket_seq = 0;
     const mi::L64Jit* l64_jit = nullptr; // the kernel compiled for this plan's masks (owned by the process-wide cache), or null
     bool l64_jit_tried = false;
     int last_stage1 = 0;  // MI_STAGE1_* of the last call
@@ -309,6 +311,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     ca.l64.linear_tiles = 0;
     ca.l64.wg_per_cu = h->opt_l64_linear;  // (MI_AIRBAND_L64_WGS: workgroups per CU of the persistent stage-1 launch, 0 = default)
     ca.l64_chan = h->d_l64_chan;
+    ca.l64_tickets = h->d_l64_tickets;
+    ca.l64_ticket_seq = &h->l64_ticket_seq;
     ca.l64_chan_full = h->d_l64_chan_full;
     if (ca.l64.enabled && !h->l64_jit_tried && h->opt_l64_jit) {  // (on first use: a handle that never runs stage 1 this way compiles nothing)
         h->l64_jit_tried = true;
@@ -731,7 +735,7 @@ void mi_demod_destroy(mi_demod* h) {
         return;
     (void)hipSetDevice(h->gpu);
     (void)hipDeviceSynchronize();  // calls may still be in flight on the handle's own streams
-    void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_t1, h->d_prune_t2, h->d_prune_rank, h->d_l64_chan, h->d_l64_chan_full, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx_set[0], h->d_cplx_set[1], h->d_carry_set[0], h->d_carry_set[1], h->d_carry_set[2], h->d_carry_set[3],
+    void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_t1, h->d_prune_t2, h->d_prune_rank, h->d_l64_chan, h->d_l64_chan_full, h->d_l64_tickets, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx_set[0], h->d_cplx_set[1], h->d_carry_set[0], h->d_carry_set[1], h->d_carry_set[2], h->d_carry_set[3],
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats,
                     h->d_rows,   h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_fullbound, h->d_afc_spec};
     for (void* p : ptrs)
@@ -886,6 +890,8 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
         TRY_OR_BAIL(hipMemcpy(h->d_l64_chan, p.l64_chan.data(), p.l64_chan.size() * sizeof(L64Chan), hipMemcpyHostToDevice));
         TRY_OR_BAIL(dalloc(&h->d_l64_chan_full, p.l64_chan_full.size()));
         TRY_OR_BAIL(hipMemcpy(h->d_l64_chan_full, p.l64_chan_full.data(), p.l64_chan_full.size() * sizeof(L64Chan), hipMemcpyHostToDevice));
+        TRY_OR_BAIL(dalloc(&h->d_l64_tickets, mi::kL64Tickets));
+        TRY_OR_BAIL(hipMemset(h->d_l64_tickets, 0, mi::kL64Tickets * sizeof(unsigned)));
     }
     TRY_OR_BAIL(hipMemcpy(h->d_levels, p.levels.data(), 256 * 4, hipMemcpyHostToDevice));
     TRY_OR_BAIL(hipMemcpy(h->d_sin, p.sin_lut, 257 * 4, hipMemcpyHostToDevice));
