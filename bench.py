@@ -239,7 +239,7 @@ def traffic_of(traffic, name):
     """PMC bytes per launch of a bench kernel name; stage 1 runs as l64_entry (the plan-compiled lane-resident kernel),
     k_channelize9p or k_channelize<...> depending on the plan and the options."""
     b = name.split("#")[0]
-    for k in ((b, "l64_entry", b + "9p") if b == "k_channelize" else (b,)):
+    for k in ((b, "l64_entry", b + "9p") if b == "k_channelize" else ((b, b + "2") if b == "k_tp_core" else (b,))):  # (k_tp_core2: the three-wave chain)
         if k in traffic:
             return traffic[k]
     return None

@@ -510,6 +510,50 @@ def test_consecutive_calls_overlap_with_early_input(pkg, monkeypatch, calls):
     assert_same(wo[0], owo, "audio")
 
 
+@pytest.mark.parametrize("spec_head,core_split,seg", [(1, 1, 512), (0, 1, 512), (1, 0, 512), (0, 0, 512), (1, 1, 2048), (1, 1, 4096)])
+def test_overlapped_calls_speculative_head_and_split_chain_keep_every_bit(pkg, monkeypatch, spec_head, core_split, seg):
+    """Overlapped calls with alternating audio buffers: the first segments of a call warm up on the previous call's planes from a
+    guessed state (MI_OPT_SPEC_HEAD) and the core chain runs on three waves (MI_OPT_CORE_SPLIT) -- or not; the carriers are
+    gated with a period that puts open squelches, decays and bursts across the call boundaries.  Audio and flags are the
+    oracle's either way, for three segment lengths (at 4096 the head is a single segment, at 2048 two)."""
+    import torch
+    monkeypatch.delenv("MI_AIRBAND_TP", raising=False)
+    monkeypatch.setenv("MI_AIRBAND_TP_SEGMENT", str(seg))
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    calls = [40, 24, 56, 8, 32]
+    nbat = sum(calls)
+    iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=5)
+    nb, owo, oaxc, _ = oracle_run(dev, chans, iq, nbat)
+    assert nb == nbat
+    pad = (iq.size + 255) // 256 * 256
+    d_iq = torch.zeros(pad, dtype=torch.uint8, device="cuda")
+    d_iq[:iq.size] = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    s = torch.cuda.current_stream().cuda_stream
+    d = pkg.Demod(dev, chans, nstreams=1, max_batches=max(calls))
+    d.set_option(pkg.OPT_EARLY_INPUT, 1)
+    d.set_option(pkg.OPT_SPEC_HEAD, spec_head)
+    d.set_option(pkg.OPT_CORE_SPLIT, core_split)
+    outs, flags, done = [], [], 0
+    for k in calls:
+        pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+        wo = torch.empty((1, len(chans), k * WAVE_BATCH), dtype=torch.float32, device="cuda")
+        ax = torch.empty((1, len(chans), k), dtype=torch.uint8, device="cuda")
+        d.process_device(d_iq.data_ptr() + pos, pad - pos, k, wo.data_ptr(), ax.data_ptr(), hip_stream=s)
+        assert d.last_path()[0] == 1  # every call time-parallel
+        outs.append(wo)
+        flags.append(ax)
+        done += k
+    torch.cuda.synchronize()
+    wo = torch.cat(outs, dim=2).cpu().numpy()
+    ax = torch.cat(flags, dim=2).cpu().numpy()
+    d.close()
+    assert (oaxc == 42).any() and (oaxc == 32).any()  # (MI_SIGNAL / MI_NO_SIGNAL: squelches open and close in the capture)
+    assert_same(ax[0], oaxc, "axcindicate")
+    assert_same(wo[0], owo, "audio")
+
+
 def test_checkpoint_between_overlapping_calls_and_timing_ages(pkg, monkeypatch):
     """A checkpoint taken while calls are in flight (it drains them), restored into a fresh handle, continues bit for bit; the
     per-kernel timings of the last three calls stay readable by age."""
