@@ -19,10 +19,15 @@
 //                                capped stays cap (the reference's own shortcut, squelch.cpp:509-510);
 //                     STEP       otherwise: the 16 samples are stepped one by one.
 //                   It stores the exact core state at every segment boundary.
+//      k_tp_core2   the same chain on three waves per channel (automatic squelch levels with a cap factor >= 1): wave 0 walks
+//                   the noise-floor recurrence ahead under a hypothesis about its operand, wave 1 walks everything else and
+//                   takes a value from wave 0 only where it can prove it is the true one, wave 2 fetches wave 0's operands.
 //  B   k_tp_seg     one lane per (channel, segment of L = 512 .. 4096 steps): the complete state machine + AM AGC + audio,
 //                   started TP_W steps early from the exact core state and a GUESSED state-machine/AGC state
 //                   (idle CLOSED).  It records the state it had at its segment start (S), runs the segment
-//                   writing audio, and records its end state (E).  Dead fields are canonicalised.
+//                   writing audio, and records its end state (E).  Dead fields are canonicalised.  The first segments of a
+//                   call start from the carried state -- or, when calls overlap (spec_head), warm up in the previous call's
+//                   arrays like all others and are checked against the carried state by the scan.
 //  C   k_tp_scan    per channel: segment k is accepted iff S_k equals E_{k-1} of an accepted predecessor
 //                   (agcavgfast only where segment k reads it; otherwise it is passed through).  By
 //                   induction from the true state at step 0 an accepted segment started from the true state,
