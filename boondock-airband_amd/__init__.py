@@ -26,6 +26,7 @@ LIB_PATH = os.path.join(_HERE, "libmi_airband.so")
 
 WAVE_RATE = 16000
 WAVE_BATCH = 2000
+MAX_IN_FLIGHT = 3  # staging slots of mi_demod_submit (mi_airband.cpp, kSlots)
 AGC_EXTRA = 100
 
 MOD_AM, MOD_NFM = 0, 1
@@ -307,7 +308,7 @@ class Demod:
         if not hasattr(self, "_tickets"):
             self._tickets = []
         self._tickets.append((keep, ptrs, wo, axc, iqo, stats))
-        while len(self._tickets) > 2:  # a third submit completed the oldest call inside the library
+        while len(self._tickets) > MAX_IN_FLIGHT:  # a further submit completed the oldest call inside the library
             self._done = getattr(self, "_done", []) + [self._tickets.pop(0)]
 
     def wait(self):

@@ -146,8 +146,11 @@ struct mi_demod {
     float* d_ctcss_coeff = nullptr;
     float* d_ctcss_q = nullptr;
     mi_channel_stats* d_stats = nullptr;
-    // staging for the host-buffer entries: two slots, so that a second call can be uploaded while the first computes
-    // (mi_demod_submit / mi_demod_wait; mi_demod_process uses slot 0 alone)
+    // staging for the host-buffer entries: three slots, so that one call can be uploaded and one downloaded while a third
+    // computes (mi_demod_submit / mi_demod_wait; mi_demod_process uses slot 0 alone).  A time-parallel call has ~2.5 ms of
+    // latency whatever its length (segment pass -> scan -> fix -> ...), so with two slots a 16-s call could not be fed faster
+    // than one per (upload + latency) / 2.
+    static constexpr int kSlots = 3;
     struct Slot {
         unsigned char* d_iq = nullptr;   // [nstreams][iq_stride]
         float* d_wout = nullptr;         // [rows][max steps + AGC_EXTRA]: emitted audio + lookahead, the host layout
@@ -165,9 +168,9 @@ struct mi_demod {
         char* axc = nullptr;
         mi_channel_stats* stats = nullptr;
         bool wave_direct = false;  // waveout is page-locked: the audio is downloaded straight into it
-    } slot[2];
+    } slot[kSlots];
     size_t iq_stride = 0, h_out_bytes = 0;
-    bool slots_ready[2] = {false, false};
+    bool slots_ready[kSlots] = {};
     int slot_next = 0, slot_oldest = 0, in_flight = 0;
     hipStream_t copy_stream = nullptr;  // uploads of submitted calls
     hipStream_t down_stream = nullptr;  // their downloads
@@ -1102,9 +1105,12 @@ int slot_launch(mi_demod* h, int k, const uint8_t* const* iq, int nbatches, bool
         HIP_TRY(hipEventRecord(sl.up_done, up));
         ready = sl.up_done;
     }
-    // the staging copy is ordered by the stream / by `ready`: MI_OPT_EARLY_INPUT (valid when the call is made) does not hold here
+    // mi_demod_process: the staging copy is ordered by the stream, MI_OPT_EARLY_INPUT (valid when the call is made) does not hold.
+    // mi_demod_submit: the upload has its own stream and event, which is all the front of the call waits for -- so consecutive
+    // submitted calls overlap on the device like device-resident calls with the option set (their audio goes to the two
+    // slots' buffers in turn, which is what lets the segment passes of one run under the tail of the other).
     const bool early = h->early_input;
-    h->early_input = false;
+    h->early_input = pipelined;
     const size_t wstride = nsteps + mi::kAgcExtra;  // the host layout: emitted audio followed by the lookahead (channel_t.waveout)
     int rc = enqueue(h, sl.d_iq, h->iq_stride, need, nbatches, sl.d_wout, wstride, want_iq ? sl.d_iqout : nullptr, nsteps, sl.d_axc, s, ready);
     h->early_input = early;
@@ -1192,7 +1198,7 @@ int mi_demod_wait(mi_demod* h) {
     HIP_TRY(hipSetDevice(h->gpu));
     const int k = h->slot_oldest;
     int rc = slot_collect(h, k);
-    h->slot_oldest ^= 1;
+    h->slot_oldest = (h->slot_oldest + 1) % mi_demod::kSlots;
     h->in_flight--;
     return rc;
 }
@@ -1202,7 +1208,7 @@ int mi_demod_submit(mi_demod* h, const uint8_t* const* iq, int nbatches, float* 
     if (rc != MI_OK)
         return rc;
     HIP_TRY(hipSetDevice(h->gpu));
-    if (h->in_flight == 2) {  // both slots taken: the oldest call completes first (its outputs become valid here)
+    if (h->in_flight == mi_demod::kSlots) {  // every slot taken: the oldest call completes first (its outputs become valid here)
         rc = mi_demod_wait(h);
         if (rc != MI_OK)
             return rc;
@@ -1220,7 +1226,7 @@ int mi_demod_submit(mi_demod* h, const uint8_t* const* iq, int nbatches, float* 
     sl.busy = true;
     if (h->in_flight == 0)
         h->slot_oldest = k;
-    h->slot_next = k ^ 1;
+    h->slot_next = (k + 1) % mi_demod::kSlots;
     h->in_flight++;
     return MI_OK;
 }

@@ -123,11 +123,12 @@ size_t mi_demod_hop_bytes(const mi_demod* h);
 int mi_demod_process(mi_demod* h, const uint8_t* const* iq, int nbatches, float* waveout, float* iq_out, char* axc,
                      mi_channel_stats* stats);
 
-/* The same call split in two, so that a host can keep two calls in flight: mi_demod_submit() starts the upload of the IQ, both
+/* The same call split in two, so that a host can keep up to three calls in flight: mi_demod_submit() starts the upload of the IQ, both
  * stages and the download of the results and returns; mi_demod_wait() completes the OLDEST submitted call -- on return that
  * call's waveout / iq_out / axc / stats hold its results.  The upload of call k+1 (its own copy stream and device buffer)
- * then runs under the compute of call k, and the download of call k under the compute of call k+1; results are identical
- * to the same calls made one after the other.  At most two calls are in flight: a third mi_demod_submit() first completes
+ * then runs under the compute of call k, and the download of call k under the compute of call k+1 (on plans that take the
+ * time-parallel stage 2, consecutive calls also overlap on the device as with MI_OPT_EARLY_INPUT); results are identical
+ * to the same calls made one after the other.  At most three calls are in flight: a fourth mi_demod_submit() first completes
  * the oldest one.  The IQ bytes must stay valid until the call has been waited for only if they live in pinned memory (see
  * mi_host_alloc); any other source is copied into the handle's staging before mi_demod_submit() returns.
  * mi_demod_process() == mi_demod_submit() + mi_demod_wait() (after completing whatever was in flight). */

@@ -1004,9 +1004,9 @@ def test_bandwidth_key_present_without_a_filter(pkg):
 
 @pytest.mark.parametrize("plan", ["config2", "zoo"])
 @pytest.mark.parametrize("pinned", [False, True])
-def test_submit_wait_keeps_two_calls_in_flight_and_every_bit(pkg, plan, pinned):
-    """mi_demod_submit / mi_demod_wait: the upload of call k+1 runs under the compute of call k on the handle's second staging
-    slot, the download of call k under call k+1.  Calls of different sizes (time-parallel and serial stage 2 on the AM plan),
+def test_submit_wait_keeps_three_calls_in_flight_and_every_bit(pkg, plan, pinned):
+    """mi_demod_submit / mi_demod_wait: the upload of call k+1 runs under the compute of call k on another of the handle's three
+    staging slots, the download of call k under call k+1, and time-parallel calls overlap on the device.  Calls of different sizes (time-parallel and serial stage 2 on the AM plan),
     from pageable and from page-locked memory (uploaded without the staging copy), a synchronous mi_demod_process in between:
     audio incl. the lookahead, flags, raw I/Q and statistics equal the same calls made one after the other, and the oracle."""
     if plan == "config2":
@@ -1040,20 +1040,19 @@ def test_submit_wait_keeps_two_calls_in_flight_and_every_bit(pkg, plan, pinned):
     d = pkg.Demod(dev, chans, max_batches=max(calls))
     sync = [d.process([iq[p:]], k, want_iq=True) for p, k in zip(positions(d), calls)]
     d.close()
-    # the same calls, two in flight; the fourth one synchronous (it first completes what is in flight)
+    # the same calls, three in flight (a fourth submit first completes the oldest inside the library); the fifth one
+    # synchronous (it first completes what is in flight)
     d = pkg.Demod(dev, chans, max_batches=max(calls))
     pos = positions(d)
     got = []
     d.submit([at(pos[0])], calls[0], want_iq=True)
     d.submit([at(pos[1])], calls[1], want_iq=True)
-    d.submit([at(pos[2])], calls[2], want_iq=True)  # completes call 0 inside
-    got.append(d.wait())
-    got.append(d.wait())
-    got.append(d.wait())
-    got.append(d.process([iq[pos[3]:]], calls[3], want_iq=True))
-    d.submit([at(pos[4])], calls[4], want_iq=True)
+    d.submit([at(pos[2])], calls[2], want_iq=True)
+    d.submit([at(pos[3])], calls[3], want_iq=True)  # completes call 0 inside
+    for _ in range(4):
+        got.append(d.wait())
+    got.append(d.process([iq[pos[4]:]], calls[4], want_iq=True))
     d.submit([at(pos[5])], calls[5], want_iq=True)
-    got.append(d.wait())
     got.append(d.wait())
     with pytest.raises(pkg.MiError):
         d.wait()

@@ -2,7 +2,7 @@
 """PCIe-inclusive rate of the host-buffer entries (the note next to `value`): capture in host memory ->
 device -> audio back to host.  Three ways: mi_demod_process from pageable memory (staging memcpy + upload + compute + download,
 one after the other), mi_demod_process from page-locked memory (no staging copy), and mi_demod_submit / mi_demod_wait from
-page-locked memory with two calls in flight (upload of call k+1 under the compute of call k).
+page-locked memory with two / three calls in flight (upload of call k+1 under the compute of call k).
 
     python tools/host_entry_rate.py [batches per call, default 128 = 16 s of signal; 1 = the reference's own cadence]"""
 import os
@@ -54,16 +54,19 @@ import numpy as np  # noqa: E402
 nwave = len(chans) * (nbat * WAVE_BATCH + AGC_EXTRA)
 outpin = pkg.PinnedBuffer(3 * nwave * 4)  # three page-locked audio buffers, used in turn
 outs = [outpin.array[i * nwave * 4:(i + 1) * nwave * 4].view(np.float32).reshape(1, len(chans), -1) for i in range(3)]
-d = pkg.Demod(dev, chans, max_batches=nbat)
-d.submit([pin.view(0)], nbat, want_stats=False, waveout=outs[0])
-t0 = None
-for call in range(1, calls):
-    d.submit([pin.view(pos(d, call))], nbat, want_stats=False, waveout=outs[call % 3])
-    d.wait()
-    if call == 1:
-        t0 = time.perf_counter()  # steady state from the second call on
-d.wait()
-per = (time.perf_counter() - t0) / (calls - 1)
-d.close()
-report("mi_demod_submit / mi_demod_wait, page-locked source and audio buffers, two calls in flight", per)
+for depth in (2, 3):  # calls kept in flight (the library has three staging slots)
+    d = pkg.Demod(dev, chans, max_batches=nbat)
+    for call in range(depth - 1):
+        d.submit([pin.view(pos(d, call))], nbat, want_stats=False, waveout=outs[call % 3])
+    t0 = None
+    for call in range(depth - 1, calls):
+        d.submit([pin.view(pos(d, call))], nbat, want_stats=False, waveout=outs[call % 3])
+        d.wait()
+        if call == depth - 1:
+            t0 = time.perf_counter()  # steady state from here on
+    for _ in range(depth - 1):
+        d.wait()
+    per = (time.perf_counter() - t0) / (calls - 1)
+    d.close()
+    report(f"mi_demod_submit / mi_demod_wait, page-locked source and audio buffers, {depth} calls in flight", per)
 pin.free()
