@@ -185,6 +185,7 @@ struct TpArgs {
     TpFinal* fin;                              // [nrows]
     int* diag;                                 // [nrows][4] segments not accepted in scan 0..3, then [nrows][4] core-chain block counts
     int seg_lpw;                               // lanes per wave of k_tp_seg, 0 = auto (MI_OPT_TP_SEG_LANES)
+    int eager_samples;                         // (diagnostic, MI_AIRBAND_TP_EAGER=1) segment lanes request every block's samples a block ahead
     int core_lead;                             // ... how many blocks its noise-floor wave may run ahead (0 = default)
     int core_split;                            // the noise-floor passes of the core chain on a wave of their own (k_tp_core2)
 };

@@ -102,6 +102,7 @@ struct mi_demod {
     double opt_tp_ratio = 0;  // MI_OPT_TP_RATIO_PCT / 100: 0 = measured default
     int opt_tp_lpw = 0;       // MI_OPT_TP_SEG_LANES: lanes per wave of the segment pass, 0 = auto
     bool opt_spec_head = true;   // MI_OPT_SPEC_HEAD: overlapped calls start their first segments from a guessed state (see TpArgs)
+    int opt_tp_eager = 0;        // (diagnostic, MI_AIRBAND_TP_EAGER)
     int opt_core_lead = 0;       // (diagnostic, MI_AIRBAND_CORE_LEAD) blocks the noise-floor wave may run ahead, 0 = default
     bool opt_core_split = true;  // MI_OPT_CORE_SPLIT: noise-floor passes of the core chain on their own wave (k_tp_core2)
     bool core_split_ok = false;  // ... the plan allows it: automatic squelch levels with a cap factor >= 1 on every channel
@@ -236,6 +237,8 @@ void tuning_from_env(mi_demod* h) {
     }
     if (const char* e = get("MI_AIRBAND_CORE_SPLIT"))
         h->opt_core_split = std::atoi(e) != 0;
+    if (const char* e = get("MI_AIRBAND_TP_EAGER"))
+        h->opt_tp_eager = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_CORE_LEAD"))
         h->opt_core_lead = std::max(0, std::atoi(e));
     if (const char* e = get("MI_AIRBAND_SPEC_HEAD"))
@@ -491,6 +494,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.seg_lpw = h->opt_tp_lpw;
         ta.core_split = (h->opt_core_split && h->core_split_ok) ? 1 : 0;
         ta.core_lead = h->opt_core_lead;
+        ta.eager_samples = h->opt_tp_eager;
         // Speculative head: when this call's segment pass may run under the previous call's tail at all (seg_early) and that call
         // left what the warm-up needs (aggregates, core states at boundaries of the same segment length, TP_W steps of them),
         // no lane starts from the carried ChanState and no launch of the pass waits for the previous call.
@@ -921,7 +925,7 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
         // segment length of the time-parallel path: short segments where rows are few (the parallelism has to come from time),
         // long ones where they are many (each lane pays TP_W steps of warm-up whatever its segment's length)
         if (h->opt_tp_L == 0)
-            h->tp_L = h->rows <= 32 ? 512u : (h->rows <= 128 ? 1024u : 2048u);
+            h->tp_L = h->rows <= 32 ? 512u : 1024u;  // (2048 beyond 128 rows until the segment pass ran full waves: DESIGN 6)
         else
             h->tp_L = static_cast<uint32_t>(h->opt_tp_L);
         h->tp_max_seg = (max_steps + h->tp_L - 1) / h->tp_L;

@@ -1265,13 +1265,19 @@ __device__ __forceinline__ void tp_run(TpLane& s, const ChanParams& p, const TpA
     const size_t bbase = static_cast<size_t>(r) * a.nblk;
     BlkAgg gn = agg_load(a, bbase + (i0 >> 4));
     BlkSamples qn = samples_load(magrow, i0);
+    bool have_n = true;
     for (uint32_t i = i0; i < i1; i += 16) {
         const BlkAgg g = gn;
         const BlkSamples q = qn;
-        const bool have = true;
+        const bool have = have_n;
         if (i + 16 < i1) {
             gn = agg_load(a, bbase + ((i + 16) >> 4));
-            qn = samples_load(magrow, i + 16);
+            // A quiet CLOSED block is settled from its aggregates alone (tp_block's first case) -- 16 bytes instead of 144.  The
+            // next block's samples are requested only if it does not look like one from here (this block's aggregates, the state
+            // before it); a block that turns out to need them after all loads them itself, once per change of regime.
+            have_n = a.eager_samples || !(s.cur == SQ_CLOSED && s.next == SQ_CLOSED && s.c == s.full && g.fm >= 0.0f && g.fm < fminf(s.cap, s.level));
+            if (have_n)
+                qn = samples_load(magrow, i + 16);
         }
         tp_block<kInSeg>(s, p, a, row, magrow, i, g, q, have, batch0, ev_slot, ev_stride);
     }
@@ -1821,10 +1827,15 @@ hipError_t launch_tp_seg(const TpArgs& a, hipStream_t s) {
         return hipSuccess;
     const int lanes = a.nrows * static_cast<int>(a.seg1 - a.seg0);
     // Lanes of one wave sit at different points of the capture, so a wave pays for every path one of its lanes takes
-    // (a squelch edge costs ~9 us per block for the whole wave).  There are far fewer lanes than the 1024 SIMDs x 64
-    // of the machine: spread them thin -- 4 per wave measured best at one stream x 8 channels (2 waves per SIMD) --
-    // and pack more only when the launch would exceed ~2 waves per SIMD.  MI_OPT_TP_SEG_LANES overrides.
+    // (a squelch edge costs ~9 us per block for the whole wave).  With a few rows there are far fewer lanes than the 1024
+    // SIMDs x 64 of the machine and nothing else competes for them: spread them thin -- 4 per wave measured best at one stream
+    // x 8 channels (2 waves per SIMD) -- and pack more only when the launch would exceed ~2 waves per SIMD.  With many rows the
+    // pass runs beside the next call's stage 1, which wants three waves per SIMD of 167 registers: every wave of this pass
+    // takes a third of a SIMD's register file out of its hands, so full waves (16 / 32 / 64 streams x 8 channels: +24 / +17 /
+    // +13 % over 16 lanes per wave).  MI_OPT_TP_SEG_LANES overrides.
     int lpw = (a.seg_lpw >= 1 && a.seg_lpw <= 64) ? a.seg_lpw : 0;
+    if (lpw == 0 && a.nrows > 32)
+        lpw = 64;
     if (lpw == 0) {
         lpw = (lanes + 2047) / 2048;
         lpw = lpw < 4 ? 4 : (lpw > 64 ? 64 : lpw);

@@ -1096,8 +1096,8 @@ def test_time_parallel_segment_lengths_keep_every_bit(pkg, monkeypatch, seg):
 
 
 def test_time_parallel_many_rows_take_long_segments_and_equal_the_oracle(pkg, monkeypatch):
-    """48 streams x 8 AM channels = 384 rows pick 2048-step segments by themselves; two overlapping calls through the device
-    entry, every stream against the oracle."""
+    """48 streams x 8 AM channels = 384 rows pick 1024-step segments and full waves in the segment pass by themselves; two
+    overlapping calls through the device entry, every stream against the oracle."""
     import torch
     monkeypatch.delenv("MI_AIRBAND_TP", raising=False)
     monkeypatch.delenv("MI_AIRBAND_TP_SEGMENT", raising=False)
