@@ -1,6 +1,8 @@
 """One-off fuzz of the time-parallel path: random plain-AM plans (SNR / manual thresholds, amplification) and captures
 (carriers from under the squelch level to clipping, random gate periods and phases), one 16-batch call (time-parallel) against
-the same capture in 4-batch calls (serial kernel): audio, flags and statistics must be identical."""
+the same capture in 4-batch calls (serial kernel): audio, flags and statistics must be identical.  Then the same capture as
+two overlapping 8-batch device calls (MI_OPT_EARLY_INPUT, two audio buffers: speculative head, chain handed over on the
+device), with the submit / wait host entry (three calls in flight) as a third reading."""
 import os
 import sys
 
@@ -54,6 +56,39 @@ for seed in range(first, last):
     wo_b = np.concatenate(outs, axis=2)
     ax_b = np.concatenate(flags, axis=2)
     same = path == 1 and np.array_equal(wo_a[:, :, :nbat * WAVE_BATCH], wo_b) and np.array_equal(ax_a, ax_b) and st_a == st_b
+    # overlapping device calls
+    import torch
+    pad = (iq.size + 255) // 256 * 256
+    d_iq = torch.zeros(pad, dtype=torch.uint8, device="cuda")
+    d_iq[:iq.size] = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    s_ = torch.cuda.current_stream().cuda_stream
+    f = pkg.Demod(dev, chans, max_batches=8)
+    f.set_option(pkg.OPT_EARLY_INPUT, 1)
+    outs, flags, paths = [], [], []
+    for call in range(2):
+        pos = 0 if call == 0 else (call * 8 * WAVE_BATCH + AGC_EXTRA) * f.hop_bytes
+        wo = torch.empty((1, len(chans), 8 * WAVE_BATCH), dtype=torch.float32, device="cuda")
+        ax = torch.empty((1, len(chans), 8), dtype=torch.uint8, device="cuda")
+        f.process_device(d_iq.data_ptr() + pos, pad - pos, 8, wo.data_ptr(), ax.data_ptr(), hip_stream=s_)
+        paths.append(f.last_path()[0])
+        outs.append(wo)
+        flags.append(ax)
+    torch.cuda.synchronize()
+    st_c = bytes(f.stats())
+    f.close()
+    wo_c = torch.cat(outs, dim=2).cpu().numpy()
+    ax_c = torch.cat(flags, dim=2).cpu().numpy()
+    same = same and paths == [1, 1] and np.array_equal(wo_c, wo_b) and np.array_equal(ax_c, ax_b) and st_c == st_b
+    # host entry, three calls in flight
+    g = pkg.Demod(dev, chans, max_batches=8)
+    for call in range(2):
+        pos = 0 if call == 0 else (call * 8 * WAVE_BATCH + AGC_EXTRA) * g.hop_bytes
+        g.submit([iq[pos:]], 8)
+    r0, r1 = g.wait(), g.wait()
+    g.close()
+    wo_d = np.concatenate([r0[0][:, :, :8 * WAVE_BATCH], r1[0][:, :, :8 * WAVE_BATCH]], axis=2)
+    same = same and np.array_equal(wo_d, wo_b) and np.array_equal(np.concatenate([r0[1], r1[1]], axis=2), ax_b) and bytes(r1[3]) == st_b
     if not same:
         bad += 1
         print("seed", seed, "MISMATCH (path", path, ")")
