@@ -554,6 +554,44 @@ def test_overlapped_calls_speculative_head_and_split_chain_keep_every_bit(pkg, m
     assert_same(wo[0], owo, "audio")
 
 
+def test_event_timeline_of_overlapping_calls(pkg, monkeypatch):
+    """mi_demod_event_ms (diagnostic): the launches of consecutive overlapped time-parallel calls in time.  Within a call stage 1
+    ends before the aggregates, those before the core chain, that before the segment pass, that before the scan; the core
+    chains of consecutive calls run in order; a call that was not time-parallel, a chunk that does not exist or an age beyond
+    the kept sets is refused."""
+    import torch
+    monkeypatch.delenv("MI_AIRBAND_TP", raising=False)
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    nbat, ncalls = 16, 4
+    iq, _ = gen_iq(pkg, dev, centre, chans, nbat * ncalls, gate_div=3)
+    pad = (iq.size + 255) // 256 * 256
+    d_iq = torch.zeros(pad, dtype=torch.uint8, device="cuda")
+    d_iq[:iq.size] = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    s = torch.cuda.current_stream().cuda_stream
+    d = pkg.Demod(dev, chans, nstreams=1, max_batches=nbat)
+    d.set_option(pkg.OPT_EARLY_INPUT, 1)
+    bufs = [(torch.empty((1, len(chans), nbat * WAVE_BATCH), dtype=torch.float32, device="cuda"),
+             torch.empty((1, len(chans), nbat), dtype=torch.uint8, device="cuda")) for _ in range(3)]
+    assert d.event_ms(0, 0, 0, 3) is None  # nothing has run yet
+    for k in range(ncalls):
+        pos = 0 if k == 0 else (k * nbat * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+        wo, ax = bufs[k % 3]
+        d.process_device(d_iq.data_ptr() + pos, pad - pos, nbat, wo.data_ptr(), ax.data_ptr(), hip_stream=s)
+    torch.cuda.synchronize()
+    for age in (2, 1, 0):
+        t = {e: d.event_ms(2, age, 0, e) for e in (0, 1, 11, 2, 3, 4, 5, 12, 10, 7, 8, 9)}
+        assert all(v is not None for v in t.values()), (age, t)
+        assert t[0] <= t[1] <= t[2] <= t[3] + 1e-3 and t[3] <= t[4] <= t[5] + 1e-3 and t[5] <= t[12] <= t[10] + 1e-3 and t[10] <= t[7] <= t[8] <= t[9], (age, t)
+    core = [(d.event_ms(2, age, 0, 3), d.event_ms(2, age, 0, 4)) for age in (2, 1, 0)]
+    assert core[0][0] == 0.0 and core[0][1] <= core[1][0] + 1e-3 and core[1][1] <= core[2][0] + 1e-3, core
+    assert d.event_ms(2, 0, 1, 3) is None   # overlapping calls of 8 rows have one chunk
+    assert d.event_ms(1, 2, 0, 3) is None   # the reference call must not be younger than the call asked about
+    assert d.event_ms(4, 0, 0, 3) is None   # beyond the kept sets
+    d.close()
+
+
 def test_checkpoint_between_overlapping_calls_and_timing_ages(pkg, monkeypatch):
     """A checkpoint taken while calls are in flight (it drains them), restored into a fresh handle, continues bit for bit; the
     per-kernel timings of the last three calls stay readable by age."""
