@@ -517,11 +517,37 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                         // full_ at its start (the hypothesis path is cheaper from there).  The leading run of acceptable
                         // blocks is committed; a block that is not is left to the general path, which is exact for any block.
                         float nfL = nf, capL = cap, cL = c;  // state after the lane's block
+                        // kSplit: the chain wave has the noise floor of these blocks already, and it is the true one wherever
+                        // capped_ stays above the floor (min() takes the floor whichever operand it was given) -- which the
+                        // lanes check as on the hypothesis path.  Then a round walks nothing but the EMA.  Taken only if the
+                        // chain wave agrees on the value this wave just computed for block kk.
+                        bool ring_ok = false;
+                        float ringv = 0.0f;
+                        if (kSplit && !solo && share_wait(sh, rb_seq, g0 + nb)) {
+                            ringv = *(lds_vf32*)&sh->nfring[(g0 + lane) & (kNfRing - 1u)];
+                            ring_ok = rl(ringv, kk) == nf;
+                        }
                         while (kk + 1 < nb && c != fe_k) {
                             constexpr int kRound = 16;
                             bool ok = false;
                             float nf_in = nf, cap_in = cap, c_in = c;
-                            if (lane > kk) {
+                            if (kSplit && ring_ok) {
+                                float em1 = 0.0f;
+                                if (lane > kk) {
+#pragma unroll 1
+                                    for (int t = 0; t < kRound; ++t) {
+                                        c_in = wave_shr1(cL, c);
+                                        float cs1;
+                                        ema_trial(yv, c_in, cs1, em1);
+                                        cL = cs1;
+                                    }
+                                }
+                                nf_in = wave_shr1(ringv, nf);  // (lane kk+1: the chain wave's value for block kk, which is nf)
+                                cap_in = cap_of(p, nf_in);
+                                nfL = ringv, capL = cap_of(p, ringv);
+                                ok = lane > kk && cur.fm >= 0.0f && em1 < capL && c_in != fe_prev &&
+                                     __builtin_fminf(c_in, nf_in) == __builtin_fminf(fe_prev, nf_in);  // (lane > 0: the chain wave's operand is fe_prev)
+                            } else if (lane > kk) {
 #pragma unroll 1
                                 for (int t = 0; t < kRound; ++t) {
                                     c_in = wave_shr1(cL, c);
