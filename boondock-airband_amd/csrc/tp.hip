@@ -283,17 +283,17 @@ __device__ __forceinline__ void ema_trial(const float (&ys)[16], const float c, 
     }
 }
 
-// ---- the core chain on two waves (k_tp_core2) ----
+// ---- the core chain on three waves (k_tp_core2: wave 0 the passes, wave 1 everything else, wave 2 wave 0's operand loads) ----
 // The noise-floor passes are 0.9 ms of the 2.0 ms a 64-s call spends in the chain; the rest is loads, verification, snapshots and
 // the stepped blocks after each burst -- work that needs capped_, which only the walking wave knows.  But the passes do not need
 // it: with the operand "full_ at the block's start" the recurrence noise_floor' = 0.97 nf + 0.03 min(operand, nf) + 1e-6 gives the
 // true value in the merged regime (capped_ == full_), in a burst (both above the floor: min() is the floor) and in a decay unless
 // full_ dips under the floor before capped_ has met it.  So wave 0 of the workgroup walks nothing but those passes, 64 blocks at a
-// time, a few groups ahead, and wave 1 does everything else exactly as the one-wave kernel does, taking the per-block values
+// time, up to 12 groups ahead, and wave 1 does everything else exactly as the one-wave kernel does, taking the per-block values
 // from a ring in LDS instead of computing them.  Every value taken is proven: a lane accepts its block only if min(true operand,
 // nf) == min(wave 0's operand, nf) bit for bit, and after blocks wave 1 advanced by itself (single blocks, decays) it compares its
 // own value with wave 0's before it takes another one.  On a disagreement wave 0 is sent back to that block with the true value
-// (~30 times per channel-minute).  Every wait is bounded; if one runs out wave 1 walks the chain itself from there (`solo`).
+// (14-16 times per channel-minute of the gated test signal).  Every wait is bounded; if one runs out wave 1 walks the chain itself from there (`solo`).
 constexpr unsigned kNfRing = 2048;
 constexpr unsigned kOpRing = 4096;
 constexpr unsigned kShareSpin = 2u * 1000u * 1000u;
