@@ -412,7 +412,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         // Chunk sizes grow geometrically: a short first chunk gets the serial core chain going early (its stage 1 +
         // aggregates are all that precedes it), later chunks are long because every wide pass has a fixed latency per
         // launch.  MI_AIRBAND_TP_CHUNKS / MI_AIRBAND_TP_RATIO override the measured defaults.
-        // An isolated call: 3 chunks growing by 1.5x.  When calls overlap the chain is already running and stage 1 of this
+        // An isolated call: 3 chunks growing by 1.5x (round 1; see below).  When calls overlap the chain is already running and stage 1 of this
         // call hides under the previous call: one chunk then -- every chunk boundary costs the chain a launch gap and the
         // tail passes on the caller's stream (scan / fix / redo / settle / finish) their fixed latencies once more, and with
         // two chunks those passes took as long per call as the chain itself (1 / 2 / 3 / 4 chunks over 20 steps: 2.21 / 2.40 /
@@ -420,8 +420,11 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         // (that is the few-rows case, where the per-channel chain is the critical path; with hundreds of rows the wide passes
         // are, and two chunks let stage 1 of the second run under the segment / fix passes of the first: 64 streams x 8
         // channels 168 vs 147 GS/s)
-        int want = overlap ? (h->rows <= 64 ? 1 : 2) : 3;
-        double ratio = overlap ? 1.0 : 1.5;
+        // (isolated calls, round 2: with the chain on three waves an isolated call is a sum of fixed latencies -- stage 1, aggregates,
+        // chain, segment pass, scan, fix, finish -- and every chunk adds the last four once more: 2 chunks, the second twice the
+        // first, 3.7 instead of 4.1 ms per 64-s call and 2.6 instead of 3.3 per 16-s call; with many rows 2, 3 and 4 are level)
+        int want = overlap ? (h->rows <= 64 ? 1 : 2) : (h->rows <= 64 ? 2 : 3);
+        double ratio = overlap ? 1.0 : (h->rows <= 64 ? 2.0 : 1.5);
         if (h->opt_tp_chunks > 0)
             want = h->opt_tp_chunks;
         if (h->opt_tp_ratio > 0)
