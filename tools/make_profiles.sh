@@ -3,7 +3,7 @@
 # --pmc) first -- bench.py quotes `traffic` from their summary --, then the bench line, the rocprofv3 kernel trace of the same
 # command, the kernel traces of the config-3 / config-4 / am64 workloads and the SQ counter passes of stage 1 on am64.
 # The PMC passes force one chunk on every call (MI_AIRBAND_TP_CHUNKS=1): that is the geometry of every timed step of
-# the bench (only the first, isolated warm-up call of a run uses three growing chunks), so the per-launch means are exact.
+# the bench (only the first, isolated warm-up call of a run uses two chunks), so the per-launch means are exact.
 # Usage: tools/make_profiles.sh [round prefix, default r02] [stages: pmc bench kt kt3 kt4 ktam sq, default all]
 set -e
 export TMPDIR=/tmp
