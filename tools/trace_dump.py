@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Every kernel of a rocprofv3 kernel trace of bench.py around the steady state, in time order: start / end relative to the
+start of the fourth-last core-chain launch, duration, queue.  Shows which launches of consecutive overlapped calls actually run
+side by side (and which only look queued: a launch that ends exactly when another does was waiting for its registers).
+Usage: rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 bench.py --workload am64 ...; python3 tools/trace_dump.py DIR"""
 import csv, glob, sys, re
 rows=[]
 for f in glob.glob(sys.argv[1]+"/**/*kernel_trace.csv", recursive=True):
