@@ -695,7 +695,8 @@ __global__ __launch_bounds__(192) void k_tp_core2(const TpArgs a) {
     float nf = a.core_carry[r].nf;
     uint32_t blk = a.blk0;
     unsigned ack = 0, idle = 0;
-    const uint32_t lead = min(static_cast<uint32_t>(a.core_lead > 0 ? a.core_lead : 768), kNfRing - 128u);  // blocks wave 0 may be ahead of wave 1
+    // blocks wave 0 may be ahead of wave 1: at least two groups (wave 1 waits for the whole group it is in), at most the ring
+    const uint32_t lead = max(128u, min(static_cast<uint32_t>(a.core_lead > 0 ? a.core_lead : 768), kNfRing - 128u));
     unsigned quit = share_peek(&sh->quit), rs = share_peek(&sh->rb_seq), w1_pos = share_peek(&sh->w1_pos), op_done = share_peek(&sh->op_done);
     for (;;) {
         const uint32_t n = min(64u, nblk - blk);
