@@ -83,6 +83,41 @@ __device__ __forceinline__ float level_of(const ChanParams& p, const float nf, c
 // =====================================================================================================
 // P1: pre_filter_.full_ by sandwich, and the per-block aggregates
 // =====================================================================================================
+// The two bounding trajectories over samples [i0, i1) (multiples of 16) of one row.  A lane walks its own stretch of the row, so
+// every load is a round trip of its own (a cache line per lane): 32 samples are requested per trip, a trip ahead of their
+// use -- with four per trip and no prefetch the pass was bound by memory latency, 1024 round trips per lane (0.57 ms alone,
+// 1.5 ms beside the other passes of a many-row call, on the front stream ahead of the next call's stage 1).
+__device__ __forceinline__ void full_warmup(const float* __restrict__ x, uint32_t i0, const uint32_t i1, float& lo, float& hi) {
+    auto step4 = [&](const float4 v) {
+        lo = ema99(lo, v.x), hi = ema99(hi, v.x);
+        lo = ema99(lo, v.y), hi = ema99(hi, v.y);
+        lo = ema99(lo, v.z), hi = ema99(hi, v.z);
+        lo = ema99(lo, v.w), hi = ema99(hi, v.w);
+    };
+    if (i0 + 32u <= i1) {
+        float4 n[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            n[j] = *reinterpret_cast<const float4*>(x + i0 + 4 * j);
+        for (; i0 + 32u <= i1; i0 += 32u) {
+            float4 c[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                c[j] = n[j];
+            if (i0 + 64u <= i1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    n[j] = *reinterpret_cast<const float4*>(x + i0 + 32u + 4 * j);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                step4(c[j]);
+        }
+    }
+    for (; i0 < i1; i0 += 4)
+        step4(*reinterpret_cast<const float4*>(x + i0));
+}
+
 __global__ __launch_bounds__(64) void k_tp_full(const TpArgs a) {
     const int lanes_per_row = (a.step1 - a.step0 + a.L - 1) / a.L;  // this chunk's lanes
     const int gid = blockIdx.x * 64 + threadIdx.x;
@@ -107,29 +142,30 @@ __global__ __launch_bounds__(64) void k_tp_full(const TpArgs a) {
             // depends on the chain state of that call, so this kernel never waits for its core launches.
             const uint32_t nprev = TP_W1 - t0;  // a multiple of 16, like prev_n
             const float* __restrict__ xp = a.prev_mag + static_cast<size_t>(row) * a.plane_stride + kAgcExtra + (a.prev_n - nprev);
-            for (uint32_t i = 0; i < nprev; i += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(xp + i);
-                lo = ema99(lo, v.x), hi = ema99(hi, v.x);
-                lo = ema99(lo, v.y), hi = ema99(hi, v.y);
-                lo = ema99(lo, v.z), hi = ema99(hi, v.z);
-                lo = ema99(lo, v.w), hi = ema99(hi, v.w);
-            }
+            full_warmup(xp, 0, nprev, lo, hi);
         }
     }
-    for (uint32_t i = tw; i < t0; i += 4) {  // warm-up (tw and t0 are multiples of 16)
-        const float4 v = *reinterpret_cast<const float4*>(x + i);
-        lo = ema99(lo, v.x), hi = ema99(hi, v.x);
-        lo = ema99(lo, v.y), hi = ema99(hi, v.y);
-        lo = ema99(lo, v.z), hi = ema99(hi, v.z);
-        lo = ema99(lo, v.w), hi = ema99(hi, v.w);
-    }
+    full_warmup(x, tw, t0, lo, hi);  // (tw and t0 are multiples of 16)
     const size_t bbase = static_cast<size_t>(r) * a.nblk;
+    float4 nb[4];  // the next block's samples, requested a block ahead
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        nb[j] = *reinterpret_cast<const float4*>(x + t0 + 4 * j);
     for (uint32_t i = t0; i < t1; i += 16) {
         const bool valid = (lo == hi);
         float fmax = 0.0f, xmin = 3.4e38f, x0 = 0.0f;
+        float4 cb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            cb[j] = nb[j];
+        if (i + 16 < t1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                nb[j] = *reinterpret_cast<const float4*>(x + i + 16 + 4 * j);
+        }
 #pragma unroll
         for (int j = 0; j < 16; j += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(x + i + j);
+            const float4 v = cb[j / 4];
             const float s[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
