@@ -63,23 +63,30 @@ for seed in range(first, last):
     d_iq[:iq.size] = torch.from_numpy(iq).cuda()
     torch.cuda.synchronize()
     s_ = torch.cuda.current_stream().cuda_stream
-    f = pkg.Demod(dev, chans, max_batches=8)
+    # (call sizes vary with the seed; every call has at least 8 batches, so all of them are time-parallel)
+    sizes = [[8, 8], [16], [8, 8], [8, 8]][seed % 4] if nbat == 16 else [nbat]
+    f = pkg.Demod(dev, chans, max_batches=max(sizes))
     f.set_option(pkg.OPT_EARLY_INPUT, 1)
-    outs, flags, paths = [], [], []
-    for call in range(2):
-        pos = 0 if call == 0 else (call * 8 * WAVE_BATCH + AGC_EXTRA) * f.hop_bytes
-        wo = torch.empty((1, len(chans), 8 * WAVE_BATCH), dtype=torch.float32, device="cuda")
-        ax = torch.empty((1, len(chans), 8), dtype=torch.uint8, device="cuda")
-        f.process_device(d_iq.data_ptr() + pos, pad - pos, 8, wo.data_ptr(), ax.data_ptr(), hip_stream=s_)
+    if seed % 5 == 0:
+        f.set_option(pkg.OPT_SPEC_HEAD, 0)
+    if seed % 7 == 0:
+        f.set_option(pkg.OPT_CORE_SPLIT, 0)
+    outs, flags, paths, done = [], [], [], 0
+    for k in sizes:
+        pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * f.hop_bytes
+        wo = torch.empty((1, len(chans), k * WAVE_BATCH), dtype=torch.float32, device="cuda")
+        ax = torch.empty((1, len(chans), k), dtype=torch.uint8, device="cuda")
+        f.process_device(d_iq.data_ptr() + pos, pad - pos, k, wo.data_ptr(), ax.data_ptr(), hip_stream=s_)
         paths.append(f.last_path()[0])
         outs.append(wo)
         flags.append(ax)
+        done += k
     torch.cuda.synchronize()
     st_c = bytes(f.stats())
     f.close()
     wo_c = torch.cat(outs, dim=2).cpu().numpy()
     ax_c = torch.cat(flags, dim=2).cpu().numpy()
-    same = same and paths == [1, 1] and np.array_equal(wo_c, wo_b) and np.array_equal(ax_c, ax_b) and st_c == st_b
+    same = same and all(p_ == 1 for p_ in paths) and np.array_equal(wo_c, wo_b) and np.array_equal(ax_c, ax_b) and st_c == st_b
     # host entry, three calls in flight
     g = pkg.Demod(dev, chans, max_batches=8)
     for call in range(2):
