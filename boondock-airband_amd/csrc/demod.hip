@@ -419,6 +419,43 @@ __device__ __forceinline__ void ema_passes16(float& F, float& C, float& T, float
 #define MI_PROF_MARK(k) do { } while (0)
 #endif
 
+// ---- the pre-filter wave (k_demod_pw) ----
+// Of what a 64-step steady block costs, the pre-filter averages + noise floor of Squelch::process_raw_sample are the largest
+// part (2 900 of 7 500 cycles on an AM channel, of 11 400 on NFM + low-pass + CTCSS): 64 dependent passes.  That recurrence
+// (sample_count_, noise_floor_, moving_avg_cap_, pre_filter_.full_ / capped_: squelch.cpp:201-214, 477-514) takes the raw
+// magnitudes and nothing else -- no squelch state, no filter, no audio.  So a second wave of the workgroup walks it over the
+// whole call, 64 steps per trip, ahead of the channel wave, and leaves every step's values in a ring in LDS; the channel wave's
+// steady blocks read their 64 lanes' values there instead of computing them (its sample loop keeps computing its own: the same
+// numbers).  Nothing is speculative: the values are those of the serial recurrence.  The pre-filter wave reads a step's
+// magnitude before the channel wave may overwrite it with the low-passed one (rtl_airband.cpp:548): the channel wave never
+// passes the pre-filter wave.
+constexpr unsigned kPreRing = 1024;  // steps
+struct PreShare {
+    float C[kPreRing], F[kPreRing], NF[kPreRing], CAP[kPreRing];  // after step i, at i % kPreRing
+    unsigned h_done;  // the pre-filter wave has delivered every step below this one
+    unsigned m_pos;   // the channel wave is at (or past) this step
+};
+typedef __attribute__((address_space(3))) PreShare LdsPre;
+typedef __attribute__((address_space(3))) volatile unsigned pre_vu32;
+typedef __attribute__((address_space(3))) volatile float pre_vf32;
+constexpr unsigned kPreSpin = 4u * 1000u * 1000u;
+__device__ __forceinline__ unsigned pre_peek(const __attribute__((address_space(3))) unsigned* p) {
+    return __builtin_amdgcn_readfirstlane(*(const pre_vu32*)p);
+}
+// channel wave: say where it is and wait until the pre-filter wave has delivered every step below `upto` (bounded)
+__device__ __forceinline__ bool pre_wait(LdsPre* pre, const int lane, const uint32_t at, const uint32_t upto) {
+    if (lane == 0)
+        *(pre_vu32*)&pre->m_pos = at;
+    for (unsigned spin = 0; pre_peek(&pre->h_done) < upto; ++spin) {
+        __builtin_amdgcn_s_sleep(1);
+        if (spin > kPreSpin) {
+            return false;
+        }
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+
 struct BlockIo {
 #ifdef MI_BLOCK_PROF
     unsigned long long prof[8];
@@ -446,7 +483,8 @@ struct BlockIo {
 //   OPEN              + has_signal() must hold; audio
 //   CLOSING           as OPEN without the has_signal() test (it is only asked when the delay runs out)
 //   LOW_SIGNAL_ABORT  averages + noise floor only
-__device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo& io, const uint32_t i0_, const int kmax_, bool& batch_open) {
+template <bool kPre>
+__device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo& io, const uint32_t i0_, const int kmax_, bool& batch_open, LdsPre* pre, const bool pre_on) {
     // wave-uniform by construction; say so, so that loop control stays on the scalar unit
     const uint32_t i0 = __builtin_amdgcn_readfirstlane(i0_);
     const int kmax = __builtin_amdgcn_readfirstlane(kmax_);
@@ -508,7 +546,19 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     float nf = s.noise_floor, cap = s.moving_avg_cap;
     float F = 0.0f, C = 0.0f, NFv = nf, CAPv = cap;
     int zero_from = 64;  // first step that cleared squelch_level_cache_
-    {
+    bool from_ring = false;
+    if constexpr (kPre) {
+        // the pre-filter wave has walked these steps (and many more): take its values
+        // (`pre` is an LDS address and may well be 0: never tested, the flag says whether the pre-filter wave is there)
+        if (pre_on && pre_wait(pre, lane, i0, i0 + static_cast<uint32_t>(kmax))) {
+            const unsigned at = (i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u);
+            C = *(pre_vf32*)&pre->C[at], F = *(pre_vf32*)&pre->F[at], NFv = *(pre_vf32*)&pre->NF[at], CAPv = *(pre_vf32*)&pre->CAP[at];
+            const int nb0 = __builtin_amdgcn_readfirstlane((15 - static_cast<int>(s.sample_count & 15u)) & 15);  // first step whose sample_count_ is a multiple of 16
+            zero_from = nb0 < kmax ? nb0 : 64;
+            from_ring = true;
+        }
+    }
+    if (!from_ring) {
         // Every lane runs every pass with its own cap: the lanes before the current sixteen-step stretch have their final
         // values and reproduce them, the first lane of the stretch finds its predecessor's final value one lane down.
         float T = s.pre_full * k99, Pc = s.pre_capped;  // what lane 0 keeps reading (its shifted source does not exist)
@@ -796,8 +846,9 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
 // kUni: one channel per wave -- all 64 lanes run it in lockstep on the same values.  It is its own instantiation so that
 // the compiler's uniformity analysis sees a row that depends on blockIdx alone: the channel state then sits in scalar
 // registers where it can, the state machine's integer work runs on the scalar unit and its branches are scalar branches.
-template <bool kUni>
-__global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
+template <bool kUni, bool kPre>
+__device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
+    bool pre_on = kPre;  // the pre-filter wave is there and delivering (k_demod_pw)
     const int rows = a.nstreams * a.nch;
     constexpr bool uni = kUni;
     const int row = kUni ? static_cast<int>(blockIdx.x) : static_cast<int>(blockIdx.x) * a.lanes_per_wave + static_cast<int>(threadIdx.x);
@@ -912,7 +963,7 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
                       kmax = 0;
                   kmax &= ~3;
                   if (kmax >= 8) {
-                      const int kc = steady_block(c, a, bio, gi * 4, kmax, batch_open);
+                      const int kc = steady_block<kPre>(c, a, bio, gi * 4, kmax, batch_open, pre, pre_on);
                       if (kc > 0) {
                           in_batch += static_cast<uint32_t>(kc);
                           if (in_batch == kWaveBatch) {
@@ -942,6 +993,19 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
               }
           }
           const uint32_t i0 = gi * 4;
+          if constexpr (kPre) {
+              if (pre_on) {
+                  // A low-pass channel rewrites wavein[] with the filtered magnitude (rtl_airband.cpp:548): it must not pass the
+                  // pre-filter wave, which reads the raw one.  Other channels only say where they are (the pre-filter wave stays
+                  // within the ring's reach of that).
+                  if (P.lowpass_enabled && zrow) {
+                      if (!pre_wait(pre, c.lane, i0, i0 + 4u))
+                          pre_on = false;  // (it never came: this wave computes everything itself from here on)
+                  } else if (c.lane == 0) {
+                      *(pre_vu32*)&pre->m_pos = i0;
+                  }
+              }
+          }
           if (stale) {
               nx = xg[gi];
               na = ag[gi];
@@ -1229,6 +1293,86 @@ __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
     }
 }
 
+template <bool kUni>
+__global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
+    demod_body<kUni, false>(a, nullptr);
+}
+
+// The pre-filter wave of k_demod_pw: the recurrence of steady_block()'s first phase, block after block over the whole call.
+__device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const int lane) {
+    const int row = static_cast<int>(blockIdx.x);
+    const ChanParams P = a.cp[row % a.nch];
+    const ChanState& s0 = a.st[row];
+    const float* __restrict__ xrow = a.mag + static_cast<size_t>(row) * a.plane_stride + kAgcExtra;
+    const uint32_t n = a.nsteps;
+    const float k99 = 0.99f, n99 = static_cast<float>(1.0 - static_cast<double>(0.99f));
+    const float k97 = 0.97f, n97 = static_cast<float>(1.0 - static_cast<double>(0.97f));
+    // the state the call starts from (wave-uniform)
+    float nf = s0.noise_floor, cap = s0.moving_avg_cap, full = s0.pre_full, capd = s0.pre_capped;
+    uint32_t sc = s0.sample_count;
+    float xn = xrow[min(static_cast<uint32_t>(lane), n - 1u)];  // the next block's samples, requested a block ahead
+    unsigned idle = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+        const int kmax = static_cast<int>(min(64u, n - i0));
+        // stay within the ring's reach of the channel wave (it posts its position before it waits for this wave)
+        while (i0 + 64u > pre_peek(&pre->m_pos) + (kPreRing - 64u)) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++idle > 4u * kPreSpin) {
+                return;  // (the channel wave is gone or stuck: it computes its own values when its wait runs out)
+            }
+        }
+        idle = 0;
+        const float x = xn;
+        xn = xrow[min(i0 + 64u + static_cast<uint32_t>(lane), n - 1u)];
+        const float b = x * n99;
+        float F = 0.0f, C = 0.0f, NFv = nf, CAPv = cap;
+        float T = full * k99, Pc = capd;  // what lane 0 keeps reading (its shifted source does not exist)
+        float CAPX = __builtin_inff();
+        int L = 0;
+        int nb = __builtin_amdgcn_readfirstlane((15 - static_cast<int>(sc & 15u)) & 15);  // first step whose sample_count_ is a multiple of 16
+        while (L < kmax) {
+            if (L == nb) {  // calculate_noise_floor with the averages step L-1 left, squelch.cpp:477-490
+                const float Cin = L ? lane_read(C, L - 1) : capd;
+                nf = nf * k97 + std_min(Cin, nf) * n97 + 1e-6f;
+                cap = P.using_manual_level ? P.manual_cap : P.cap_factor * nf;
+                nb += 16;
+            }
+            const int E = min(nb, kmax);
+            const bool mine = lane >= L;
+            NFv = mine ? nf : NFv;
+            CAPv = mine ? cap : CAPv;
+            CAPX = mine ? (x >= cap ? cap : __builtin_inff()) : CAPX;
+            ema_passes16(F, C, T, Pc, b, CAPv, CAPX);
+            L = E;
+        }
+        if (lane < kmax) {
+            const unsigned at = (i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u);
+            *(pre_vf32*)&pre->C[at] = C, *(pre_vf32*)&pre->F[at] = F, *(pre_vf32*)&pre->NF[at] = NFv, *(pre_vf32*)&pre->CAP[at] = CAPv;
+        }
+        asm volatile("" ::: "memory");
+        if (lane == 0)
+            *(pre_vu32*)&pre->h_done = i0 + static_cast<uint32_t>(kmax);
+        // the state the next block starts from
+        full = lane_read(F, kmax - 1);
+        capd = lane_read(C, kmax - 1);
+        sc += static_cast<uint32_t>(kmax);
+    }
+}
+
+// One channel per workgroup of two waves: the channel itself (as k_demod<true>) and the pre-filter wave ahead of it.
+__global__ __launch_bounds__(128) void k_demod_pw(const DemodArgs a) {
+    __shared__ PreShare sh_mem;
+    LdsPre* const pre = (LdsPre*)&sh_mem;
+    if (threadIdx.x == 0)
+        pre->h_done = 0, pre->m_pos = 0;
+    __syncthreads();
+    if (threadIdx.x >= 64) {
+        pre_wave(a, pre, static_cast<int>(threadIdx.x) - 64);
+        return;
+    }
+    demod_body<true, true>(a, pre);
+}
+
 __global__ void k_init_state(ChanState* st, float* carry, float* sq_ring, float* ctcss_q, const ChanParams* cp, int nstreams, int nch,
                              int n_ctcss_rows) {
     const int rows = nstreams * nch;
@@ -1297,7 +1441,9 @@ hipError_t launch_demod(const DemodArgs& a, hipStream_t s) {
     if (rows == 0 || a.nsteps == 0)
         return hipSuccess;
     const int blocks = (rows + a.lanes_per_wave - 1) / a.lanes_per_wave;
-    if (a.lanes_per_wave == 1)
+    if (a.lanes_per_wave == 1 && a.pre_wave && a.steady_blocks)
+        hipLaunchKernelGGL(k_demod_pw, dim3(blocks), dim3(128), 0, s, a);
+    else if (a.lanes_per_wave == 1)
         hipLaunchKernelGGL(k_demod<true>, dim3(blocks), dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL(k_demod<false>, dim3(blocks), dim3(64), 0, s, a);

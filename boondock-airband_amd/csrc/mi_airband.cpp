@@ -101,6 +101,7 @@ struct mi_demod {
     int opt_tp_chunks = 0;    // MI_OPT_TP_CHUNKS: 0 = measured default
     double opt_tp_ratio = 0;  // MI_OPT_TP_RATIO_PCT / 100: 0 = measured default
     int opt_tp_lpw = 0;       // MI_OPT_TP_SEG_LANES: lanes per wave of the segment pass, 0 = auto
+    int opt_pre_wave = -1;       // MI_OPT_PRE_WAVE: serial kernel, one channel per wave: a second wave walks the squelch pre-filter ahead (k_demod_pw); -1 = up to 512 rows
     bool opt_spec_head = true;   // MI_OPT_SPEC_HEAD: overlapped calls start their first segments from a guessed state (see TpArgs)
     int opt_tp_eager = 0;        // (diagnostic, MI_AIRBAND_TP_EAGER)
     int opt_core_lead = 0;       // (diagnostic, MI_AIRBAND_CORE_LEAD) blocks the noise-floor wave may run ahead, 0 = default
@@ -241,6 +242,8 @@ void tuning_from_env(mi_demod* h) {
         h->opt_tp_eager = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_CORE_LEAD"))
         h->opt_core_lead = std::max(0, std::atoi(e));
+    if (const char* e = get("MI_AIRBAND_PRE_WAVE"))
+        h->opt_pre_wave = std::atoi(e) < 0 ? -1 : (std::atoi(e) != 0 ? 1 : 0);
     if (const char* e = get("MI_AIRBAND_SPEC_HEAD"))
         h->opt_spec_head = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_L64"))
@@ -376,6 +379,10 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     da.fm_quadri = h->plan.dev.fm_quadri;
     da.lanes_per_wave = lanes_per_wave_for(h);
     da.steady_blocks = h->steady_blocks ? 1 : 0;
+    // the pre-filter wave pays where a call is bound by the latency of its rows (4 / 8 / 16 streams x 32 mixed channels: +44 / +37 /
+    // +12 %); with a thousand rows and more the machine is full and a second wave per row only takes LDS and issue slots from
+    // stage 1 (32 streams: +-0, 64 streams: -27 %)
+    da.pre_wave = (h->opt_pre_wave < 0 ? h->rows <= 512 : h->opt_pre_wave != 0) ? 1 : 0;
 
     // the serial kernels expect the carried AGC_EXTRA samples of every row at the front of the planes they work on
     auto head_in_place = [&]() -> int {
@@ -1553,6 +1560,9 @@ int mi_demod_set_option(mi_demod* h, int option, int value) {
             return MI_OK;
         case MI_OPT_SPEC_HEAD:
             h->opt_spec_head = value != 0;
+            return MI_OK;
+        case MI_OPT_PRE_WAVE:
+            h->opt_pre_wave = value < 0 ? -1 : (value != 0 ? 1 : 0);
             return MI_OK;
         case MI_OPT_LANE_FFT_JIT:
             h->opt_l64_jit = value != 0;

@@ -236,6 +236,9 @@ enum {
     MI_OPT_SPEC_HEAD = 13,    /* 1 (default): when consecutive calls overlap (MI_OPT_EARLY_INPUT, alternating audio buffers) the first segments
                                * of a call warm up on the previous call's samples from a guessed state, as all others do, instead of waiting
                                * for the state that call's tail leaves; the scan checks them against it afterwards */
+    MI_OPT_PRE_WAVE = 14,     /* serial stage 2 with one channel per wave: a second wave per channel walks the squelch's pre-filter averages and
+                               * noise floor over the call ahead of the channel's own wave (demod.hip, k_demod_pw).  -1 (default): up to 512
+                               * rows (streams x channels), 0 never, 1 always */
     MI_OPT_LANE_FFT_JIT = 11  /* 1 (default): that kernel is compiled for the plan's own FFT nodes by hipRTC on first use (the code object is
                                * cached per (device, hop, masks) for the life of the process); 0, or hipRTC missing: the prebuilt full graph */
 };
