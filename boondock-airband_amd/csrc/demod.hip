@@ -1241,9 +1241,9 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
     }
 
 #ifdef MI_BLOCK_PROF
-    if (kUni && row == 0 && threadIdx.x == 0)
-        printf("blockprof row0: total %llu cyc, %llu blocks, %llu of %u steps in blocks; after-return %llu loads %llu between blocks %llu pre %llu level+lsc %llu filter %llu post %llu audio %llu commit %llu\n",
-               __builtin_readcyclecounter() - prof_k0, bio.blocks, bio.steps, n, bio.after_ret, bio.prof[6], bio.prof[7], bio.prof[0], bio.prof[1], bio.prof[2], bio.prof[3], bio.prof[4], bio.prof[5]);
+    if (kUni && threadIdx.x == 0)
+        printf("blockprof row %d (mod %d lp %d ctcss %d notch %d): total %llu cyc, %llu blocks, %llu of %u steps in blocks; after-return %llu loads %llu between blocks %llu pre %llu level+lsc %llu filter %llu post %llu audio %llu commit %llu\n",
+               row, (int)P.modulation, (int)P.lowpass_enabled, (int)P.ctcss_enabled, (int)P.notch_enabled, __builtin_readcyclecounter() - prof_k0, bio.blocks, bio.steps, n, bio.after_ret, bio.prof[6], bio.prof[7], bio.prof[0], bio.prof[1], bio.prof[2], bio.prof[3], bio.prof[4], bio.prof[5]);
 #endif
     // plane carry: the last AGC_EXTRA (possibly low-pass-rewritten) magnitudes and raw bins move to the front,
     // the reference's memmove (rtl_airband.cpp:643-646)
