@@ -180,6 +180,12 @@ const L64Jit* l64_jit_get(int device, int hop, const uint64_t need[6], const cha
     }
     e->jit.minwaves = minwaves;
     e->usable = true;
+    if (std::getenv("MI_AIRBAND_DEBUG")) {
+        int regs = -1;
+        (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, e->jit.fn);
+        std::fprintf(stderr, "mi_airband: lane-resident stage 1 compiled for this plan: %d live classes, %d waves per SIMD asked for, %d VGPRs\n",
+                     __builtin_popcountll(need[5]), minwaves, regs);
+    }
     return &e->jit;
 }
 
