@@ -189,6 +189,7 @@ struct TpArgs {
     int eager_samples;                         // (diagnostic, MI_AIRBAND_TP_EAGER=1) segment lanes request every block's samples a block ahead
     int core_lead;                             // ... how many blocks its noise-floor wave may run ahead (0 = default)
     int core_split;                            // the noise-floor passes of the core chain on a wave of their own (k_tp_core2)
+    int core_guess;                            // ... taken by guess-and-verify rounds instead of systolic passes (nf_chain_guess64)
 };
 inline uint32_t tp_chunk_unit(uint32_t L) {  // lcm(L, WAVE_BATCH = 2000) for L = 2^k >= 16: 2000 = 16 * 125
     return L * 125u;

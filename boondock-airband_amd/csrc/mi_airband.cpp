@@ -105,6 +105,7 @@ struct mi_demod {
     bool opt_spec_head = true;   // MI_OPT_SPEC_HEAD: overlapped calls start their first segments from a guessed state (see TpArgs)
     int opt_tp_eager = 0;        // (diagnostic, MI_AIRBAND_TP_EAGER)
     int opt_core_lead = 0;       // (diagnostic, MI_AIRBAND_CORE_LEAD) blocks the noise-floor wave may run ahead, 0 = default
+    int opt_core_guess = 1;      // (diagnostic, MI_AIRBAND_CORE_GUESS=0) the noise-floor wave walks systolic passes only, no guess-and-verify rounds
     bool opt_core_split = true;  // MI_OPT_CORE_SPLIT: noise-floor passes of the core chain on their own wave (k_tp_core2)
     bool core_split_ok = false;  // ... the plan allows it: automatic squelch levels with a cap factor >= 1 on every channel
     bool opt_l64 = true;      // MI_OPT_LANE_FFT: the lane-resident stage 1 at N = 512 where the plan allows it
@@ -186,6 +187,8 @@ struct mi_demod {
     int* d_rec[kSets] = {};  // per scratch set: the segment passes of the next call write theirs while this call's tail reads its own
     const float* prev_out_lo = nullptr;  // audio buffer of the previous call (its tail may still be writing it)
     const float* prev_out_hi = nullptr;
+    const float* set_out_lo[kSets] = {};  // ... and of the time-parallel calls that used each scratch set last
+    const float* set_out_hi[kSets] = {};
     int* d_tstart = nullptr;
     int* d_need = nullptr;
     mi::TpFinal* d_fin = nullptr;
@@ -242,6 +245,8 @@ void tuning_from_env(mi_demod* h) {
         h->opt_tp_eager = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_CORE_LEAD"))
         h->opt_core_lead = std::max(0, std::atoi(e));
+    if (const char* e = get("MI_AIRBAND_CORE_GUESS"))
+        h->opt_core_guess = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_PRE_WAVE"))
         h->opt_pre_wave = std::atoi(e) < 0 ? -1 : (std::atoi(e) != 0 ? 1 : 0);
     if (const char* e = get("MI_AIRBAND_SPEC_HEAD"))
@@ -504,6 +509,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.seg_lpw = h->opt_tp_lpw;
         ta.core_split = (h->opt_core_split && h->core_split_ok) ? 1 : 0;
         ta.core_lead = h->opt_core_lead;
+        ta.core_guess = h->opt_core_guess;
         ta.eager_samples = h->opt_tp_eager;
         // Speculative head: when this call's segment pass may run under the previous call's tail at all (seg_early) and that call
         // left what the warm-up needs (aggregates, core states at boundaries of the same segment length, TP_W steps of them),
@@ -590,8 +596,20 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             // from it), the audio lookahead (written by the last segments) and the caller's audio buffer if it is the
             // one the previous call wrote.
             HIP_TRY(hipStreamWaitEvent(ss, ev(i, 4), 0));
-            if (seg_early && h->set_seq[before_prev])  // the call before the previous one is complete (two audio buffers alternate)
-                HIP_TRY(hipStreamWaitEvent(ss, h->ev[before_prev][2], 0));
+            if (seg_early) {
+                // The pass writes the caller's audio buffer: the last call that wrote the same memory has to be complete (its fades
+                // rewrite audio).  Not the previous call (seg_early); with two buffers alternating the one before it, with three the
+                // one before that -- then the pass has two tail periods of slack instead of one and the tails run back to back.
+                for (int back = 1; back < mi_demod::kSets - 1; ++back) {
+                    const int pq = (h->cur + mi_demod::kSets - back) % mi_demod::kSets;
+                    if (!h->set_seq[pq])
+                        break;
+                    if (h->set_path[pq] != 1 || !(out_hi <= h->set_out_lo[pq] || out_lo >= h->set_out_hi[pq])) {
+                        HIP_TRY(hipStreamWaitEvent(ss, h->ev[pq][2], 0));
+                        break;
+                    }
+                }
+            }
             // (events 5 -> 12 time the pass itself: they sit inside every wait of the segment stream; of a split first chunk
             // the body is timed, its few head segments are not)
             const uint32_t head_end = std::min<uint32_t>(c.seg1, mi::TP_W / L + 1);
@@ -633,6 +651,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         h->chain_live = true;
         h->prev_out_lo = out_lo;
         h->prev_out_hi = out_hi;
+        h->set_out_lo[q] = out_lo;
+        h->set_out_hi[q] = out_hi;
     } else if (h->plan.any_afc) {
         if (iq_ready)
             HIP_TRY(hipStreamWaitEvent(s, iq_ready, 0));

@@ -281,9 +281,89 @@ __device__ __forceinline__ float nf_chain_scaled(const float nf, const float sca
     return v;
 }
 
+// ---- the noise-floor chain of a full group, guess and verify (k_tp_core2, wave 0) ----
+// In a quiet or a saturated stretch almost every step is the SELF step nf' = fl(fl(fl(nf*0.97) + fl(nf*0.03)) + 1e-6), and because 0.97f + (1 - 0.97f)
+// is exactly 1 that is "the bit pattern of nf plus a constant" (67 in [0.125, 0.25): round(1e-6 / ulp)) except where the first product lies
+// within 1/64 ulp of a tie -- then it is one less or one more.  The pattern of those exceptions is a slow rotation (the product's fraction
+// moves by -0.01 per step and is kicked by +0.03 by every exception): none for ~70 steps, then one every third step for hundreds
+// (tests/studies/nf_chain_study.py).  So the lanes GUESS: with the floor entering block kk known, lane j takes
+//     g_j = nf_kk + h0 + h1 + h2 + h0 + ... (j - kk terms; on the bit patterns; h = the increments of the last three settled blocks)
+// as the floor entering its block and computes the TRUE step o_j = F_j(g_j) from it with its own operand.  Lane kk's input is exact; if
+// o_{j-1} == g_j for kk < j <= l, the inputs of lanes kk .. l are exact by induction, hence so are o_kk .. o_l -- including o_l, whose
+// successor guessed wrong.  A round therefore settles the run up to and including the first lane whose result is not the next guess
+// (a step below the floor, an exception the history did not predict), and the next round starts behind it.  Nothing is approximate: a
+// value is used only after every step before it has been taken for real from a proven input.  About 3 rounds of ~30 instructions per
+// 64 blocks on the bench signal instead of 64 passes of 6; a group whose rounds stay short is finished by the systolic passes.
+struct NfGuess {
+    uint32_t dh;  // per lane: the last regular increment (inc-1 .. inc+1 on the bit pattern) seen three blocks before, six, ... (0 = none)
+};
+__device__ __forceinline__ uint32_t wave_shr1_u32(const uint32_t v, const uint32_t first) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(first), static_cast<int>(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t wave_shl1_u32(const uint32_t v, const uint32_t last) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(last), static_cast<int>(v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t mul24(const uint32_t x, const uint32_t y) {
+    return __umul24(x, y);
+}
+// Returns per lane the noise floor after the lane's block (all 64 lanes), leaves the floor after block 63 in nf.
+__device__ __forceinline__ float nf_chain_guess64(float& nf, const float op, NfGuess& gs, const int lane, int& n_rounds) {
+    uint32_t nfb = __builtin_amdgcn_readfirstlane(__float_as_uint(nf));
+    const uint32_t inc = __builtin_amdgcn_readfirstlane(__float_as_uint(__uint_as_float(nfb) + 1e-6f)) - nfb;
+    float vnf = nf;
+    // a lane without a regular increment yet (or with one from another binade) expects the plain self step
+    uint32_t dh = (gs.dh + 1u - inc <= 2u) ? gs.dh : inc;
+    // the predictions of the first round: the increments of the previous group's last three blocks (lanes 60 .. 62 after the shift
+    // at its end)
+    uint32_t h0 = __builtin_amdgcn_readlane(dh, 60), h1 = __builtin_amdgcn_readlane(dh, 61), h2 = __builtin_amdgcn_readlane(dh, 62);
+    int kk = 0, rounds = 0;
+    for (;;) {
+        // lane kk + n: the sum of the n predicted increments h0, h1, h2, h0, ...
+        const uint32_t n = static_cast<uint32_t>(lane - kk);
+        const uint32_t q = mul24(n, 43u) >> 7;  // n / 3 for n < 128 (lanes below kk: anything)
+        const uint32_t r = n - mul24(q, 3u);
+        const uint32_t part = (r == 0u) ? 0u : ((r == 1u) ? h0 : h0 + h1);
+        const uint32_t g = nfb + mul24(q, h0 + h1 + h2) + part;
+        const float o = noise_floor_step(__uint_as_float(g), op);
+        const uint32_t ob = __float_as_uint(o);
+        const uint32_t oprev = wave_shr1_u32(ob, 0u);
+        // bit i: lane i + 1 exists, lies behind kk and its guess is not the true result of the lane before
+        const unsigned long long bad = ((__ballot(oprev != g) >> 1) | (1ull << 63)) & (~0ull << kk);
+        // lanes kk .. (first bad bit) had a proven input: no bad bit below the lane (mbcnt: set bits of the mask below the lane)
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(bad >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bad), 0u));
+        const bool settled = below == 0u && lane >= kk;
+        const int last = __ffsll(static_cast<long long>(bad)) - 1;
+        if (settled)
+            vnf = o;
+        const uint32_t d = ob - g;
+        if (settled && d + 1u - inc <= 2u)
+            dh = d;
+        nfb = __builtin_amdgcn_readlane(ob, last);
+        kk = last + 1;
+        ++rounds;
+        if (kk >= 64)
+            break;
+        if (__builtin_expect(rounds >= 8, 0)) {  // the history does not predict this stretch: systolic passes for the rest of the group
+            if (lane >= kk)
+                vnf = nf_chain_min(__uint_as_float(nfb), op, 64 - kk);
+            nfb = __builtin_amdgcn_readlane(__float_as_uint(vnf), 63);
+            break;
+        }
+        // the increments of the last three settled blocks (a lane that took a step below the floor keeps what it had before)
+        h0 = __builtin_amdgcn_readlane(dh, (last + 62) & 63), h1 = __builtin_amdgcn_readlane(dh, (last + 63) & 63), h2 = __builtin_amdgcn_readlane(dh, last);
+    }
+    n_rounds += rounds;
+    // the next group's lane j is block 64 + j; 63 is a multiple of three, so lane j + 1 of this group is the same class
+    gs.dh = wave_shl1_u32(dh, inc);
+    nf = __uint_as_float(nfb);
+    return vnf;
+}
+
 struct CoreGroup {  // what lane l holds for block g0 + l
     float fe, fm, x0, xm;
-    float4 s0, s1, s2, s3;  // the block's 16 raw samples (only read when the block has to be stepped)
+};
+struct CoreSamples {  // the block's 16 raw samples: only read when a block of the group has to be stepped, and loaded then
+    float4 s0, s1, s2, s3;
 };
 
 __device__ __forceinline__ CoreGroup core_load(const TpArgs& a, const float* __restrict__ x, const size_t bbase, const uint32_t g0, const int lane) {
@@ -297,9 +377,14 @@ __device__ __forceinline__ CoreGroup core_load(const TpArgs& a, const float* __r
     const float fm = a.blk_fm[bbase + at];
     g.x0 = a.blk_x0[bbase + at];
     g.xm = a.blk_xm[bbase + at];
+    g.fm = mine < a.blk1 ? fm : -1.0f;
+    return g;
+}
+__device__ __forceinline__ CoreSamples core_samples(const TpArgs& a, const float* __restrict__ x, const uint32_t g0, const int lane) {
+    CoreSamples g;
+    const uint32_t at = min(g0 + lane, a.blk1 - 1u);
     const float4* __restrict__ sp = reinterpret_cast<const float4*>(x + static_cast<size_t>(at) * 16);
     g.s0 = sp[0], g.s1 = sp[1], g.s2 = sp[2], g.s3 = sp[3];
-    g.fm = mine < a.blk1 ? fm : -1.0f;
     return g;
 }
 
@@ -330,13 +415,27 @@ __device__ __forceinline__ void ema_trial(const float (&ys)[16], const float c, 
 // nf) == min(wave 0's operand, nf) bit for bit, and after blocks wave 1 advanced by itself (single blocks, decays) it compares its
 // own value with wave 0's before it takes another one.  On a disagreement wave 0 is sent back to that block with the true value
 // (14-16 times per channel-minute of the gated test signal).  Every wait is bounded; if one runs out wave 1 walks the chain itself from there (`solo`).
+#ifdef MI_CORE_PROF
+#define CORE_PROF(...) __VA_ARGS__
+__device__ __forceinline__ unsigned long long prof_now() {
+    return wall_clock64();  // 100 MHz
+}
+#else
+#define CORE_PROF(...)
+#endif
 constexpr unsigned kNfRing = 2048;
-constexpr unsigned kOpRing = 4096;
+constexpr unsigned kOpRing = 2048;
+constexpr unsigned kFetchTrip = 512;  // blocks a fetch wave requests at a time (32 loads per lane in flight)
 constexpr unsigned kShareSpin = 2u * 1000u * 1000u;
 struct CoreShare {
     float nfring[kNfRing];  // noise floor after block b, at b % kNfRing
-    float opring[kOpRing];  // wave 0's operand of block b (full_ at its start), at b % kOpRing: fetched by wave 2
-    unsigned op_done;       // wave 2 has delivered the operands of every block below this one
+    // The block aggregates of k_tp_full, staged by the two fetch waves (waves 2 and 3) -- a lone wave that loads its own with two groups
+    // in flight walks a group per 0.73 us whatever it does with it: the latency of the loads.
+    float opring[kOpRing];  // full_ at the START of block b (= blk_fe of b - 1; the carried value for the chunk's first): wave 0's operand
+    float fmring[kOpRing];  // blk_fm of block b (-1 past the end)
+    float x0ring[kOpRing];  // blk_x0
+    float xmring[kOpRing];  // blk_xm
+    unsigned fetch_next[2];  // per fetch wave: first block of the trip it has not delivered yet (everything below both is there)
     unsigned w0_done;       // wave 0 has delivered every block below this one (since its last restart)
     unsigned w1_pos;        // block wave 1 is at: wave 0 stays within the ring's reach of it
     unsigned rb_seq, rb_ack, rb_blk;  // restart request of wave 1 / its acknowledgement
@@ -409,25 +508,110 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
     const uint32_t bps_log = 31u - static_cast<uint32_t>(__builtin_clz(bps));
 
     int n_run = 0, n_single = 0, n_step = 0, n_fail = 0;  // diagnostics: blocks per path, failed hypotheses
+    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_wait = 0, t_stepping = 0, t_mark = 0; int n_waits = 0;)
     // kSplit: the noise-floor passes come from the chain wave (CoreShare).  `own`: this wave advanced the noise floor itself since it
     // last took a value from there (single blocks, decays): the next value taken is only good if the chain wave agrees on the one
     // before it.  `solo`: the chain wave was given up on (a wait ran out): from then on this wave walks the chain itself.
     bool own = false, solo = !kSplit;
     unsigned rb_seq = 0;
+    uint32_t done_seen = a.blk0;  // blocks the chain wave is known to have delivered (forgotten when it is sent back)
     float fe_group = full;  // full_ at the start of the group: the chain wave's operand for the group's first block
     int n_rollback = 0;
-    CoreGroup nxt = core_load(a, x, bbase, a.blk0, lane);
-    CoreGroup nxt2 = core_load(a, x, bbase, a.blk0 + 64, lane);
+    CoreGroup nxt, nxt2;
+    if (!kSplit) {
+        nxt = core_load(a, x, bbase, a.blk0, lane);
+        nxt2 = core_load(a, x, bbase, a.blk0 + 64, lane);
+    }
+    uint32_t fetch_seen = a.blk0;  // kSplit: blocks whose aggregates the fetch waves are known to have delivered
     for (uint32_t g0 = a.blk0; g0 < nblk; g0 += 64) {
-        const CoreGroup cur = nxt;
-        nxt = nxt2;
-        nxt2 = core_load(a, x, bbase, g0 + 128, lane);  // two groups in flight while this one is walked (past the end: the last block again)
+        CoreGroup cur;
+        float fe_prev;  // full_ at the start of lane's block, valid for lane > kk
+        if (kSplit) {
+            // the group's aggregates from the rings (entry b of opring is full_ at the start of block b, so blk_fe of b is entry b + 1)
+            if (fetch_seen < g0 + 65u) {
+                for (unsigned spin = 0;; ++spin) {
+                    fetch_seen = min(share_peek(&sh->fetch_next[0]), share_peek(&sh->fetch_next[1]));
+                    if (fetch_seen >= g0 + 65u || spin > 8u * kShareSpin)
+                        break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                share_order();
+            }
+            const uint32_t slot = (g0 + lane) & (kOpRing - 1u), slot1 = (g0 + lane + 1u) & (kOpRing - 1u);
+            fe_prev = *(lds_vf32*)&sh->opring[slot];
+            cur.fe = *(lds_vf32*)&sh->opring[slot1];
+            cur.fm = *(lds_vf32*)&sh->fmring[slot];
+            cur.x0 = *(lds_vf32*)&sh->x0ring[slot];
+            cur.xm = *(lds_vf32*)&sh->xmring[slot];
+        } else {
+            cur = nxt;
+            nxt = nxt2;
+            nxt2 = core_load(a, x, bbase, g0 + 128, lane);  // two groups in flight while this one is walked (past the end: the last block again)
+            fe_prev = wave_shr1(cur.fe, 0.0f);
+        }
         const int nb = static_cast<int>(min(64u, nblk - g0));
-        const float fe_prev = wave_shr1(cur.fe, 0.0f);  // full_ at the start of lane's block, valid for lane > kk
         const bool boundary = ((g0 + lane) & (bps - 1u)) == 0;  // (bps is a power of two)
-        bool ys_ready = false;
+        // A group of a quiet or a saturated stretch is settled from its aggregates alone.  The raw samples are requested when the
+        // first block of the group has to be stepped -- or at its start when the group before ended in the middle of a decay.
+        bool ys_ready = false, smp_ready = false;
         float yv[16];
+        CoreSamples smp;
+        if (c != full && c != cap) {
+            smp = core_samples(a, x, g0, lane);
+            smp_ready = true;
+        }
         int kk = 0;
+        if (kSplit && nb == 64 && !solo && !own) {
+            // ---- a whole group in one regime: the hypothesis path below with kk = 0 and all 64 lanes passing, as straight-line code
+            // (that path is general and branchy: 0.55 us per group on a lone wave; this one is ~40 instructions).  Anything else --
+            // a lane that fails, a group after blocks this wave stepped itself, a partial group -- is left to the general path.
+            nf = uni(nf), cap = uni(cap), c = uni(c), full = uni(full);
+            const bool merged = (c == full);
+            if (merged || c == cap) {
+                if (lane == 0)
+                    share_post(&sh->w1_pos, g0);
+                if (done_seen < g0 + 64u) {  // (the chain wave is usually several groups ahead: one look covers them)
+                    CORE_PROF(t_mark = prof_now(); ++n_waits;)
+                    for (unsigned spin = 0;; ++spin) {
+                        done_seen = share_peek(&sh->w0_done);
+                        if (done_seen >= g0 + 64u || spin > kShareSpin)
+                            break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    share_order();
+                    CORE_PROF(t_wait += prof_now() - t_mark;)
+                }
+                if (done_seen >= g0 + 64u) {
+                    const float vnf = *(lds_vf32*)&sh->nfring[(g0 + lane) & (kNfRing - 1u)];
+                    const float nf_prev = wave_shr1(vnf, nf);
+                    const float cap_prev = (lane == 0) ? cap : cap_of(p, nf_prev);
+                    const float capj = cap_of(p, vnf);
+                    const float full_entry = (lane == 0) ? full : fe_prev;
+                    const float c_entry = merged ? full_entry : cap_prev;
+                    const float opw = (lane > 0) ? fe_prev : fe_group;
+                    bool ok = cur.fm >= 0.0f && __builtin_fminf(c_entry, nf_prev) == __builtin_fminf(opw, nf_prev);
+                    if (merged)
+                        ok = ok && c_entry < capj && cur.fm < capj;
+                    else
+                        ok = ok && capped_step(c_entry, cur.x0, capj) == capj && cur.xm >= capj;
+                    if (__ballot(ok) == ~0ull) {
+                        if (boundary) {
+                            TpCore t;
+                            t.nf = nf_prev, t.cap = cap_prev, t.c = c_entry, t.full = full_entry;
+                            core[(g0 + lane) >> bps_log] = t;
+                        }
+                        nf = rl(vnf, 63);
+                        cap = cap_of(p, nf);
+                        full = rl(cur.fe, 63);
+                        c = merged ? full : cap;
+                        n_run += 64;
+                        ++n_single;
+                        fe_group = full;
+                        continue;
+                    }
+                }
+            }
+        }
         while (kk < nb) {
             // (wave-uniform by construction; saying so lets the branches below be scalar ones)
             nf = uni(nf), cap = uni(cap), c = uni(c), full = uni(full);
@@ -449,12 +633,15 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                         const uint32_t at = g0 + kk;
                         if (at > a.blk0 && !(share_wait(sh, rb_seq, at) && uni(*(lds_vf32*)&sh->nfring[(at - 1u) & (kNfRing - 1u)]) == nf)) {
                             solo = !share_rollback(sh, rb_seq, at, nf) || solo;
+                            done_seen = at;
                             ++n_rollback;
                         }
                         own = false;
                     }
+                    CORE_PROF(t_mark = prof_now(); ++n_waits;)
                     if (!solo && !share_wait(sh, rb_seq, g0 + nb))
                         solo = true;
+                    CORE_PROF(t_wait += prof_now() - t_mark;)
                     if (!solo && lane >= kk)
                         vnf = *(lds_vf32*)&sh->nfring[(g0 + lane) & (kNfRing - 1u)];
                 }
@@ -506,6 +693,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                 ++n_fail;
             }
             // one block, no hypothesis
+            CORE_PROF(const unsigned long long t_step0 = prof_now();)
             own = true;
             const uint32_t blk = g0 + kk;
             if ((blk & (bps - 1u)) == 0 && lane == 0) {
@@ -527,13 +715,17 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                 full = fe;
             } else {  // STEP: the 16 samples one by one
                 ++n_step;
+                if (!smp_ready) {
+                    smp = core_samples(a, x, g0, lane);
+                    smp_ready = true;
+                }
                 if (valid) {  // full_ at the block end is already known exactly: only the capped_ chain is serial
                     // Everything that does not depend on c is done once per group, by all 64 lanes for their own blocks
                     // (y = x*b); a stepped block then costs 16 lane reads and the chain.
                     if (!ys_ready) {
                         const float nfac = static_cast<float>(1.0 - static_cast<double>(0.99f));
-                        const float xv[16] = {cur.s0.x, cur.s0.y, cur.s0.z, cur.s0.w, cur.s1.x, cur.s1.y, cur.s1.z, cur.s1.w,
-                                              cur.s2.x, cur.s2.y, cur.s2.z, cur.s2.w, cur.s3.x, cur.s3.y, cur.s3.z, cur.s3.w};
+                        const float xv[16] = {smp.s0.x, smp.s0.y, smp.s0.z, smp.s0.w, smp.s1.x, smp.s1.y, smp.s1.z, smp.s1.w,
+                                              smp.s2.x, smp.s2.y, smp.s2.z, smp.s2.w, smp.s3.x, smp.s3.y, smp.s3.z, smp.s3.w};
 #pragma unroll
                         for (int j = 0; j < 16; ++j)
                             yv[j] = xv[j] * nfac;
@@ -624,9 +816,9 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                         fe = fe_k;
                     } else {
                         // capped_step() with the shortcut "c >= cap && x >= cap" as "c >= t", t = cap where x >= cap, +inf elsewhere
-                        const float xs[16] = {rl(cur.s0.x, kk), rl(cur.s0.y, kk), rl(cur.s0.z, kk), rl(cur.s0.w, kk), rl(cur.s1.x, kk), rl(cur.s1.y, kk),
-                                              rl(cur.s1.z, kk), rl(cur.s1.w, kk), rl(cur.s2.x, kk), rl(cur.s2.y, kk), rl(cur.s2.z, kk), rl(cur.s2.w, kk),
-                                              rl(cur.s3.x, kk), rl(cur.s3.y, kk), rl(cur.s3.z, kk), rl(cur.s3.w, kk)};
+                        const float xs[16] = {rl(smp.s0.x, kk), rl(smp.s0.y, kk), rl(smp.s0.z, kk), rl(smp.s0.w, kk), rl(smp.s1.x, kk), rl(smp.s1.y, kk),
+                                              rl(smp.s1.z, kk), rl(smp.s1.w, kk), rl(smp.s2.x, kk), rl(smp.s2.y, kk), rl(smp.s2.z, kk), rl(smp.s2.w, kk),
+                                              rl(smp.s3.x, kk), rl(smp.s3.y, kk), rl(smp.s3.z, kk), rl(smp.s3.w, kk)};
 #pragma unroll
                         for (int j = 0; j < 16; ++j) {
                             const float t = (xs[j] >= cap) ? cap : __int_as_float(0x7f800000);
@@ -637,9 +829,9 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                     }
                     full = fe;
                 } else {
-                    const float xs[16] = {rl(cur.s0.x, kk), rl(cur.s0.y, kk), rl(cur.s0.z, kk), rl(cur.s0.w, kk), rl(cur.s1.x, kk), rl(cur.s1.y, kk),
-                                          rl(cur.s1.z, kk), rl(cur.s1.w, kk), rl(cur.s2.x, kk), rl(cur.s2.y, kk), rl(cur.s2.z, kk), rl(cur.s2.w, kk),
-                                          rl(cur.s3.x, kk), rl(cur.s3.y, kk), rl(cur.s3.z, kk), rl(cur.s3.w, kk)};
+                    const float xs[16] = {rl(smp.s0.x, kk), rl(smp.s0.y, kk), rl(smp.s0.z, kk), rl(smp.s0.w, kk), rl(smp.s1.x, kk), rl(smp.s1.y, kk),
+                                          rl(smp.s1.z, kk), rl(smp.s1.w, kk), rl(smp.s2.x, kk), rl(smp.s2.y, kk), rl(smp.s2.z, kk), rl(smp.s2.w, kk),
+                                          rl(smp.s3.x, kk), rl(smp.s3.y, kk), rl(smp.s3.z, kk), rl(smp.s3.w, kk)};
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         full = ema99(full, xs[j]);
@@ -648,9 +840,12 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                 }
             }
             ++kk;
+            CORE_PROF(t_stepping += prof_now() - t_step0;)
         }
         fe_group = rl(cur.fe, 63);
     }
+    CORE_PROF(if (lane == 0 && r < 8) printf("core w1 row %d: total %llu us  wait-w0 %llu us (%d waits)  stepping %llu us  run %d accepted-runs %d step %d fail %d rollback %d solo %d\n", r,
+                                           (prof_now() - t_begin) / 100, t_wait / 100, n_waits, t_stepping / 100, n_run, n_single, n_step, n_fail, n_rollback, (int)solo);)
     if (kSplit && lane == 0)
         share_post(&sh->quit, 1u);
     if (lane == 0) {
@@ -672,12 +867,12 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
     core_walk<false>(a, nullptr, threadIdx.x);
 }
 
-__global__ __launch_bounds__(192) void k_tp_core2(const TpArgs a) {
+__global__ __launch_bounds__(256) void k_tp_core2(const TpArgs a) {
     __shared__ CoreShare sh_mem;
     LdsShare* const sh = (LdsShare*)&sh_mem;
     if (threadIdx.x == 0) {
         sh->w0_done = a.blk0, sh->w1_pos = a.blk0, sh->rb_seq = 0, sh->rb_ack = 0, sh->rb_blk = a.blk0, sh->rb_nf = 0.0f, sh->quit = 0;
-        sh->op_done = a.blk0;
+        sh->fetch_next[0] = a.blk0, sh->fetch_next[1] = a.blk0;
     }
     __syncthreads();
     if (threadIdx.x >= 64 && threadIdx.x < 128) {
@@ -689,37 +884,52 @@ __global__ __launch_bounds__(192) void k_tp_core2(const TpArgs a) {
     const size_t bbase = static_cast<size_t>(r) * a.nblk;
     const uint32_t nblk = a.blk1;
     if (threadIdx.x >= 128) {
-        // ---- wave 2: the operands of wave 0, 256 blocks per trip, as far ahead of wave 1 as the ring reaches.  (Wave 0 could
-        // load them itself, but only with the loads of several groups in flight across its loop, and the compiler's wait
-        // bookkeeping turns that into a wait for the newest load at every group; a wave that does nothing else may wait.)
+        // ---- waves 2 and 3: the aggregates of every block into the rings, kFetchTrip blocks per trip and wave in turn, as far ahead of
+        // wave 1 as the rings reach.  Entry b of opring is full_ at the start of block b, so the entries run to b = blk1 inclusive.
+        const unsigned w = (threadIdx.x >= 192) ? 1u : 0u;
         const float full0 = a.core_carry[r].full;
-        uint32_t f = a.blk0;
+        uint32_t f = a.blk0 + w * kFetchTrip;
         unsigned idle = 0;
+        constexpr int kPer = kFetchTrip / 64;
         for (;;) {
             const unsigned quit = share_peek(&sh->quit), w1_pos = share_peek(&sh->w1_pos);
             if (quit)
                 break;
-            if (f >= nblk || f + 256u > w1_pos + (kOpRing - 64u)) {  // done, or the ring is full (blocks behind wave 1 are free)
-                __builtin_amdgcn_s_sleep(4);
+            if (f > nblk) {  // nothing left for this wave
+                if (lane == 0)
+                    share_post(&sh->fetch_next[w], 0xffffffffu);
+                break;
+            }
+            if (f + kFetchTrip > w1_pos + (kOpRing - 64u)) {  // the ring is full (blocks behind wave 1 are free)
+                __builtin_amdgcn_s_sleep(2);
                 if (++idle > 8u * kShareSpin)
                     break;
                 continue;
             }
             idle = 0;
-            float v[4];
+            float vo[kPer], vm[kPer], v0[kPer], vx[kPer];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < kPer; ++i) {
                 const uint32_t idx = f + 64u * i + lane;
-                const float fe = a.blk_fe[bbase + (idx > 0u ? min(idx, nblk) - 1u : 0u)];  // full_ at the start of block idx
-                v[i] = (idx == a.blk0) ? full0 : fe;  // the chunk's first block: the carried value
+                const uint32_t at = min(idx, nblk - 1u);
+                vo[i] = a.blk_fe[bbase + (idx > 0u ? min(idx, nblk) - 1u : 0u)];
+                vm[i] = a.blk_fm[bbase + at];
+                v0[i] = a.blk_x0[bbase + at];
+                vx[i] = a.blk_xm[bbase + at];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *(lds_vf32*)&sh->opring[(f + 64u * i + lane) & (kOpRing - 1u)] = v[i];
+            for (int i = 0; i < kPer; ++i) {
+                const uint32_t idx = f + 64u * i + lane;
+                const uint32_t slot = idx & (kOpRing - 1u);
+                *(lds_vf32*)&sh->opring[slot] = (idx == a.blk0) ? full0 : vo[i];  // the chunk's first block: the carried value
+                *(lds_vf32*)&sh->fmring[slot] = (idx < nblk) ? vm[i] : -1.0f;
+                *(lds_vf32*)&sh->x0ring[slot] = v0[i];
+                *(lds_vf32*)&sh->xmring[slot] = vx[i];
+            }
             share_order();
-            f += 256u;
+            f += 2u * kFetchTrip;
             if (lane == 0)
-                share_post(&sh->op_done, f);
+                share_post(&sh->fetch_next[w], f > nblk ? 0xffffffffu : f);
         }
         return;
     }
@@ -731,19 +941,26 @@ __global__ __launch_bounds__(192) void k_tp_core2(const TpArgs a) {
     float nf = a.core_carry[r].nf;
     uint32_t blk = a.blk0;
     unsigned ack = 0, idle = 0;
+    NfGuess gs = {0u};
+    int n_rounds = 0;
+    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_idle = 0, t_mark = 0, t_finish = 0; int n_groups = 0, n_restarts = 0; bool idling = false;)
     // blocks wave 0 may be ahead of wave 1: at least two groups (wave 1 waits for the whole group it is in), at most the ring
     const uint32_t lead = max(128u, min(static_cast<uint32_t>(a.core_lead > 0 ? a.core_lead : 768), kNfRing - 128u));
-    unsigned quit = share_peek(&sh->quit), rs = share_peek(&sh->rb_seq), w1_pos = share_peek(&sh->w1_pos), op_done = share_peek(&sh->op_done);
+    unsigned quit = share_peek(&sh->quit), rs = share_peek(&sh->rb_seq), w1_pos = share_peek(&sh->w1_pos),
+             op_done = min(share_peek(&sh->fetch_next[0]), share_peek(&sh->fetch_next[1]));
     for (;;) {
         const uint32_t n = min(64u, nblk - blk);
         const bool go = !quit && rs == ack && blk < nblk && blk + 64u <= w1_pos + lead && op_done >= blk + n;
         if (__builtin_expect(!go, 0)) {
             if (quit)
                 break;
+            CORE_PROF(if (!idling) { idling = true; t_mark = prof_now(); if (blk >= nblk && !t_finish) t_finish = t_mark; })
             if (rs != ack) {  // wave 1 disagrees from block rb_blk on: start again there with its noise floor
                 share_order();
                 blk = share_peek(&sh->rb_blk);
                 nf = *(lds_vf32*)&sh->rb_nf;
+                gs.dh = 0u;  // (the blocks before the restart point were not this chain's)
+                CORE_PROF(++n_restarts;)
                 ack = rs;
                 if (lane == 0)
                     share_post(&sh->w0_done, blk);
@@ -755,29 +972,39 @@ __global__ __launch_bounds__(192) void k_tp_core2(const TpArgs a) {
                 if (++idle > 8u * kShareSpin)
                     break;  // (wave 1 never came: it gives up on its side as well)
             }
-            quit = share_peek(&sh->quit), rs = share_peek(&sh->rb_seq), w1_pos = share_peek(&sh->w1_pos), op_done = share_peek(&sh->op_done);
+            quit = share_peek(&sh->quit), rs = share_peek(&sh->rb_seq), w1_pos = share_peek(&sh->w1_pos);
+            op_done = min(share_peek(&sh->fetch_next[0]), share_peek(&sh->fetch_next[1]));
             continue;
         }
         idle = 0;
+        CORE_PROF(if (idling) { idling = false; t_idle += prof_now() - t_mark; } ++n_groups;)
         const float op = *(lds_vf32*)&sh->opring[(blk + lane) & (kOpRing - 1u)];
         // (the next trip's view of the other waves: in flight during the passes)
         const unsigned quit_n = *(const lds_vu32*)&sh->quit, rs_n = *(const lds_vu32*)&sh->rb_seq, w1_n = *(const lds_vu32*)&sh->w1_pos,
-                       opd_n = *(const lds_vu32*)&sh->op_done;
+                       opd_n = *(const lds_vu32*)&sh->fetch_next[0], opd_n1 = *(const lds_vu32*)&sh->fetch_next[1];
         // If every operand of the group lies above anything the chain can reach in 64 steps from here (it grows by less than
         // 1e-6 (1 + 2^-23) + 2^-22 of itself per step while min() takes the chain value), min() is the identity throughout and
         // the pass needs one instruction less: the same operations in the same order, bit for bit.
-        const bool above = n == 64u && __ballot(op >= nf * 1.0001f + 7e-5f) == ~0ull;
-        const float vnf = above ? nf_chain_self64(nf) : ((n == 64u) ? nf_chain_min64(nf, op) : nf_chain_min(nf, op, static_cast<int>(n)));
+        float vnf;
+        if (a.core_guess && n == 64u) {
+            vnf = nf_chain_guess64(nf, op, gs, lane, n_rounds);
+        } else {
+            const bool above = n == 64u && __ballot(op >= nf * 1.0001f + 7e-5f) == ~0ull;
+            vnf = above ? nf_chain_self64(nf) : ((n == 64u) ? nf_chain_min64(nf, op) : nf_chain_min(nf, op, static_cast<int>(n)));
+            nf = rl(vnf, static_cast<int>(n) - 1);
+            gs.dh = 0u;
+        }
         if (lane < static_cast<int>(n))
             *(lds_vf32*)&sh->nfring[(blk + lane) & (kNfRing - 1u)] = vnf;
         share_order();
         if (lane == 0)
             share_post(&sh->w0_done, blk + n);
-        nf = rl(vnf, static_cast<int>(n) - 1);
         blk += n;
         quit = __builtin_amdgcn_readfirstlane(quit_n), rs = __builtin_amdgcn_readfirstlane(rs_n);
-        w1_pos = __builtin_amdgcn_readfirstlane(w1_n), op_done = __builtin_amdgcn_readfirstlane(opd_n);
+        w1_pos = __builtin_amdgcn_readfirstlane(w1_n), op_done = min(__builtin_amdgcn_readfirstlane(opd_n), __builtin_amdgcn_readfirstlane(opd_n1));
     }
+    CORE_PROF(if (lane == 0 && r < 8) printf("core w0 row %d: finished after %llu us  idle before that %llu us  groups %d rounds %d restarts %d\n", r, (t_finish - t_begin) / 100, t_idle / 100, n_groups,
+                                           n_rounds, n_restarts);)
 }
 
 // =====================================================================================================
@@ -1881,7 +2108,7 @@ hipError_t launch_tp_core(const TpArgs& a, hipStream_t s) {
     if (a.nrows == 0 || a.step1 <= a.step0)
         return hipSuccess;
     if (a.core_split)
-        TP_LAUNCH(k_tp_core2, a.nrows, 192);
+        TP_LAUNCH(k_tp_core2, a.nrows, 256);
     else
         TP_LAUNCH(k_tp_core, a.nrows, 64);
     return hipSuccess;
