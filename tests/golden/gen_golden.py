@@ -5,7 +5,7 @@ built by `make -C oracle ref` from /root/reference/src/{squelch,ctcss,filters,lo
 Run in the build container only (the reference does not travel to the GPU box):
     python tests/golden/gen_golden.py
 The committed .npz holds inputs-by-seed parameters and the reference's OUTPUTS (flags, levels, filter
-outputs, counters) -- data, no reference source.  tests/test_oracle_golden.py replays the same seeded
+outputs, counters) -- data, no reference source.  tests/test_oracle_components.py replays the same seeded
 inputs through the oracle and requires identical bits; that pins the oracle on machines without _ref.
 """
 import os
