@@ -96,7 +96,7 @@ class MixInput(C.Structure):  # mi_mix_input
 
 
 ABI_SYMBOLS = [
-    "mi_last_error", "mi_device_count", "mi_demod_create", "mi_demod_destroy", "mi_demod_bytes_needed", "mi_demod_bytes_consumed",
+    "mi_last_error", "mi_device_count", "mi_demod_create", "mi_demod_destroy", "mi_demod_prepare", "mi_set_cache_dir", "mi_jit_counts", "mi_demod_bytes_needed", "mi_demod_bytes_consumed",
     "mi_demod_hop_bytes", "mi_demod_process", "mi_demod_submit", "mi_demod_wait", "mi_host_alloc", "mi_host_free", "mi_demod_process_device", "mi_demod_get_stats", "mi_demod_state_size",
     "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_last_stage1", "mi_demod_tp_debug", "mi_demod_kernel_time", "mi_demod_kernel_time_prev", "mi_demod_event_ms", "mi_demod_set_option", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
     "mi_plan_window", "mi_plan_twiddles", "mi_plan_levels", "mi_plan_sincos_lut", "mi_plan_channel", "mi_plan_ctcss_coeffs",
@@ -119,6 +119,9 @@ def lib():
         L.mi_device_count.restype = C.c_int
         L.mi_demod_create.argtypes = [C.POINTER(DeviceCfg), C.POINTER(ChannelCfg), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.mi_demod_destroy.argtypes = [vp]
+        L.mi_demod_prepare.argtypes = [vp, C.c_int]
+        L.mi_set_cache_dir.argtypes = [C.c_char_p]
+        L.mi_jit_counts.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mi_demod_last_stage1.argtypes = [vp, C.POINTER(C.c_int)]
         L.mi_demod_submit.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
         L.mi_demod_wait.argtypes = [vp]
@@ -347,6 +350,10 @@ class Demod:
         _check(lib().mi_demod_last_path(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def prepare(self, host_slots=1):
+        """mi_demod_prepare: stage-1 kernel of the plan + the staging of `host_slots` host-buffer calls, before the first batch."""
+        _check(lib().mi_demod_prepare(self._h, host_slots))
+
     def last_stage1(self):
         """MI_STAGE1_* of the last call: 0 / 1 exchange kernels (full / pruned), 2 / 3 lane-resident (full graph / plan-compiled)."""
         k = C.c_int(-1)
@@ -430,6 +437,18 @@ def iqgen_host(cfg, stream_id, first, count):
 
 def iqgen_device(cfg, first_stream_id, nstreams, stream_stride, first, count, d_out_ptr, hip_stream=None):
     _check(lib().mi_iqgen_device(C.byref(cfg), first_stream_id, nstreams, stream_stride, first, count, d_out_ptr, hip_stream))
+
+
+def set_cache_dir(path):
+    """mi_set_cache_dir: where compiled stage-1 kernels are kept between process starts (None / "" = nowhere)."""
+    _check(lib().mi_set_cache_dir(None if path is None else os.fsencode(path)))
+
+
+def jit_counts():
+    """(kernels compiled by this process, kernels loaded from the cache directory)"""
+    a, b = C.c_int(0), C.c_int(0)
+    _check(lib().mi_jit_counts(C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 class Gather:

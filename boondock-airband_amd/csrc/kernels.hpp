@@ -214,6 +214,8 @@ int l64_zstride(int m6);
 // null when hipRTC is missing or the compilation fails -- `why` then says so)
 const L64Jit* l64_jit_get(int device, int hop, const uint64_t need[6], const char** why);
 int l64_jit_minwaves(const L64Jit* j);
+void l64_jit_set_cache_dir(const char* dir);            // null / "": no code objects on disk
+void l64_jit_counts(int* compiled, int* from_disk);     // kernels compiled / loaded from the cache directory by this process
 hipError_t l64_jit_launch(const L64Jit* j, const L64Args& a, unsigned gx, unsigned gy, size_t lds, hipStream_t s);
 hipError_t launch_demod(const DemodArgs& a, hipStream_t s);
 hipError_t launch_init_state(ChanState* st, float* carry, float* sq_ring, float* ctcss_q, const ChanParams* cp, int nstreams, int nch,

@@ -263,6 +263,18 @@ void tuning_from_env(mi_demod* h) {
     }
 }
 
+int slot_prepare(mi_demod* h, int k);  // (defined with the host-buffer entries below)
+
+// The plan's own instance of the lane-resident stage 1 (hipRTC, or the code object an earlier start left on disk): 0.3-0.6 s
+// when it has to be compiled, so it is asked for when the handle is created -- before any input thread fills a ring.
+void stage1_compile(mi_demod* h) {
+    if (h->l64_jit_tried || !h->opt_l64_jit || !h->opt_l64 || !h->plan.l64.enabled || !h->d_l64_chan)
+        return;
+    h->l64_jit_tried = true;
+    const int hop = static_cast<int>(h->plan.hop_bytes / (2 * static_cast<size_t>(h->plan.bytes_per_sample)));
+    h->l64_jit = mi::l64_jit_get(h->gpu, hop, h->plan.l64.need, nullptr);
+}
+
 int lanes_per_wave_for(const mi_demod* h) {
     // up to opt_uni_rows waves keep one channel each (the uniform instantiation of k_demod); beyond that pack lanes
     int lpw = (h->rows + h->opt_uni_rows - 1) / h->opt_uni_rows;
@@ -328,11 +340,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     ca.l64_tickets = h->d_l64_tickets;
     ca.l64_ticket_seq = &h->l64_ticket_seq;
     ca.l64_chan_full = h->d_l64_chan_full;
-    if (ca.l64.enabled && !h->l64_jit_tried && h->opt_l64_jit) {  // (on first use: a handle that never runs stage 1 this way compiles nothing)
-        h->l64_jit_tried = true;
-        const int hop = static_cast<int>(h->plan.hop_bytes / (2 * static_cast<size_t>(h->plan.bytes_per_sample)));
-        h->l64_jit = mi::l64_jit_get(h->gpu, hop, h->plan.l64.need, nullptr);
-    }
+    if (ca.l64.enabled)  // (normally done by mi_demod_create; here only if the option was switched on afterwards)
+        stage1_compile(h);
     ca.l64_jit = h->opt_l64_jit ? h->l64_jit : nullptr;
     // The prebuilt full-graph instance keeps all 64 points of a lane live and is slower than the exchange kernels: it runs
     // only when asked for (MI_OPT_LANE_FFT_JIT = 0, tests); without hipRTC the pruned / full exchange kernels take over.
@@ -416,7 +425,6 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         const float* out_hi = d_wmain + static_cast<size_t>(h->rows - 1) * wmain_stride + da.nsteps;
         // segment passes may run under the previous call's tail only if they write a different audio buffer
         const bool seg_early = overlap && (out_hi <= h->prev_out_lo || out_lo >= h->prev_out_hi);
-        const int before_prev = (h->cur + mi_demod::kSets - 1) % mi_demod::kSets;
         const uint32_t n = da.nsteps;
         const uint32_t L = h->tp_L;
         const uint32_t chunk_unit = mi::tp_chunk_unit(L);
@@ -993,7 +1001,99 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     TRY_OR_BAIL(mi::launch_init_state(h->d_state, h->d_carry, h->d_ring, h->d_ctcss_q, h->d_cp, nstreams, nch, p.n_ctcss_rows, h->own_stream));
     TRY_OR_BAIL(hipStreamSynchronize(h->own_stream));
 #undef TRY_OR_BAIL
+    if (!p.any_afc)
+        stage1_compile(h);  // (a failure leaves the exchange kernels: never an error)
     *out = h;
+    return MI_OK;
+}
+
+int mi_demod_prepare(mi_demod* h, int host_slots) {
+    if (!h)
+        return fail(MI_ERR_INVALID, "NULL handle");
+    if (host_slots < 0 || host_slots > mi_demod::kSlots)
+        return fail(MI_ERR_INVALID, "host_slots out of range (0 .. 3)");
+    HIP_TRY(hipSetDevice(h->gpu));
+    stage1_compile(h);
+    for (int k = 0; k < host_slots; ++k) {
+        const int rc = slot_prepare(h, k);
+        if (rc != MI_OK)
+            return rc;
+    }
+    // The runtime gives a stream its hardware queue (and a copy engine its first transfer) when the stream is first used: a few
+    // milliseconds each.  One small operation on every stream of the handle now, so that the first batch does not pay for them.
+    unsigned* d_warm = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_warm), 256));
+    std::vector<hipStream_t> streams = {h->own_stream, h->aux_stream, h->front_stream, h->copy_stream, h->down_stream};
+    for (hipStream_t ss : h->seg_stream)
+        streams.push_back(ss);
+    hipError_t e = hipSuccess;
+    for (hipStream_t st : streams)
+        if (st && e == hipSuccess)
+            e = hipMemsetAsync(d_warm, 0, 256, st);
+    if (e == hipSuccess && host_slots > 0 && h->copy_stream && h->down_stream) {
+        e = hipMemcpyAsync(d_warm, h->slot[0].h_in, 64, hipMemcpyHostToDevice, h->copy_stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(h->copy_stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(h->slot[0].h_out, d_warm, 64, hipMemcpyDeviceToHost, h->down_stream);
+    }
+    for (hipStream_t st : streams)
+        if (st && e == hipSuccess)
+            e = hipStreamSynchronize(st);
+    (void)hipFree(d_warm);
+    HIP_TRY(e);
+    // ... and one rehearsal of the call itself (the first dispatch of a kernel on a queue sets up its scratch and kernel-argument
+    // memory: 7 ms on the first batch otherwise).  The handle's state is saved before and restored after: a prepared handle is
+    // bit for bit the handle mi_demod_create returned.
+    std::vector<unsigned char> saved(mi_demod_state_size(h));
+    int rc = mi_demod_get_state(h, saved.data(), saved.size());
+    if (rc != MI_OK)
+        return rc;
+    std::vector<int> rehearsals = {1};
+    if (h->tp_eligible && h->opt_tp != 0 && h->max_batches >= kTpMinBatches)
+        rehearsals.push_back(kTpMinBatches);
+    for (const int nb : rehearsals) {
+        const size_t need = mi_demod_bytes_needed(h, nb);
+        const size_t stride = (need + 255) & ~static_cast<size_t>(255);
+        const size_t nsteps = static_cast<size_t>(nb) * mi::kWaveBatch, rows = static_cast<size_t>(h->rows);
+        unsigned char* d_iq = nullptr;
+        float *d_wo = nullptr, *d_iqo = nullptr;
+        char* d_axc = nullptr;
+        e = hipMalloc(reinterpret_cast<void**>(&d_iq), stride * h->nstreams);
+        if (e == hipSuccess)
+            e = hipMemset(d_iq, 0x80, stride * h->nstreams);
+        if (e == hipSuccess)
+            e = hipMalloc(reinterpret_cast<void**>(&d_wo), rows * nsteps * 4);
+        if (e == hipSuccess)
+            e = hipMalloc(reinterpret_cast<void**>(&d_iqo), rows * nsteps * 8);
+        if (e == hipSuccess)
+            e = hipMalloc(reinterpret_cast<void**>(&d_axc), rows * static_cast<size_t>(nb));
+        if (e == hipSuccess) {
+            rc = mi_demod_process_device(h, d_iq, stride, nb, d_wo, d_iqo, d_axc, h->own_stream);
+            if (rc == MI_OK)
+                e = hipDeviceSynchronize();
+        }
+        void* tmp[] = {d_iq, d_wo, d_iqo, d_axc};
+        for (void* q : tmp)
+            if (q)
+                (void)hipFree(q);
+        if (rc == MI_OK && e == hipSuccess)
+            rc = mi_demod_set_state(h, saved.data(), saved.size());
+        else if (rc == MI_OK)
+            rc = fail(MI_ERR_HIP, hipGetErrorString(e));
+        if (rc != MI_OK)
+            return rc;
+    }
+    return MI_OK;
+}
+
+int mi_set_cache_dir(const char* dir) {
+    mi::l64_jit_set_cache_dir(dir);
+    return MI_OK;
+}
+
+int mi_jit_counts(int* compiled, int* from_cache) {
+    mi::l64_jit_counts(compiled, from_cache);
     return MI_OK;
 }
 

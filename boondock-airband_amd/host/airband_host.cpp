@@ -172,6 +172,8 @@ int init_demod(demod_params_t* params, Signal* signal, int device_start, int dev
         dc.fm_quadri = fm_quadri_demod_selected;
         std::vector<mi_channel_cfg> cc = channel_cfgs_of(dev);
         int rc = mi_demod_create(&dc, cc.data(), dev->channel_count, 1, 1, gpu, &dev->engine);
+        if (rc == MI_OK)
+            rc = mi_demod_prepare(dev->engine, 1);  // staging + a rehearsal now: the first batch must not pay for them
         if (rc != MI_OK) {
             fprintf(stderr, "init_demod: device %d: %s\n", d, mi_last_error());
             return rc;

@@ -101,6 +101,21 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
                     mi_demod** out);
 void mi_demod_destroy(mi_demod* h);
 
+/* Everything slow happens before the first batch: like init_demod() (rtl_airband.cpp:1058-1082) this runs before the input
+ * threads start, because the reference's ring holds only 0.5 s of u8 IQ (config.cpp:799-805; overflow: input-helpers.cpp:56-61).
+ *   mi_demod_create   also obtains the stage-1 kernel of the handle's own channel plan (fft_size 512): compiled with hipRTC
+ *                     (0.3-0.6 s) or, from the second process start on, loaded from the code-object cache (milliseconds).
+ *   mi_demod_prepare  additionally allocates the page-locked staging of `host_slots` (0 .. 3) host-buffer calls in flight
+ *                     (mi_demod_process needs 1, mi_demod_submit / _wait up to 3); without it a slot is allocated by the first
+ *                     call that uses it.  The first mi_demod_process of a prepared handle does no allocation and no compilation.
+ *   mi_set_cache_dir  where code objects are kept (process-wide; call before mi_demod_create).  NULL or "" switches the cache
+ *                     off.  Default: $MI_AIRBAND_CACHE_DIR, else $XDG_CACHE_HOME/mi_airband, else ~/.cache/mi_airband.  A file
+ *                     is keyed by GPU architecture, runtime version, plan and kernel source, written atomically, checked on load.
+ *   mi_jit_counts     kernels this process compiled / loaded from the cache (diagnostic). */
+int mi_demod_prepare(mi_demod* h, int host_slots);
+int mi_set_cache_dir(const char* dir);
+int mi_jit_counts(int* compiled, int* from_cache);
+
 /* Ring accounting for the caller (rtl_airband.cpp:416-417, 691).  A call producing nbatches batches
  * runs n_fft windows, hop_bytes apart, the last one fft_size samples long:
  *   needed   = (n_fft-1)*hop_bytes + 2*bytes_per_sample*fft_size   contiguous bytes from the stream position
