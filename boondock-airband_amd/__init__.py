@@ -98,7 +98,7 @@ class MixInput(C.Structure):  # mi_mix_input
 ABI_SYMBOLS = [
     "mi_last_error", "mi_device_count", "mi_demod_create", "mi_demod_destroy", "mi_demod_prepare", "mi_set_cache_dir", "mi_jit_counts", "mi_demod_bytes_needed", "mi_demod_bytes_consumed",
     "mi_demod_hop_bytes", "mi_demod_process", "mi_demod_submit", "mi_demod_wait", "mi_host_alloc", "mi_host_free", "mi_demod_process_device", "mi_demod_get_stats", "mi_demod_state_size",
-    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_last_path", "mi_demod_last_stage1", "mi_demod_tp_debug", "mi_demod_kernel_time", "mi_demod_kernel_time_prev", "mi_demod_event_ms", "mi_demod_set_option", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
+    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_process_planes", "mi_demod_last_path", "mi_demod_last_stage1", "mi_demod_tp_debug", "mi_demod_kernel_time", "mi_demod_kernel_time_prev", "mi_demod_event_ms", "mi_demod_set_option", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
     "mi_plan_window", "mi_plan_twiddles", "mi_plan_levels", "mi_plan_sincos_lut", "mi_plan_channel", "mi_plan_ctcss_coeffs",
     "mi_iqgen_host", "mi_iqgen_device", "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_is_stereo", "mi_mixer_process_device",
     "mi_gather_unique_id", "mi_gather_create", "mi_gather_destroy", "mi_gather_audio", "mi_gather_stream_wait", "mi_gather_sync",
@@ -281,6 +281,9 @@ class Demod:
             if a.size < need:
                 raise ValueError(f"stream shorter than bytes_needed ({a.size} < {need})")
         ptrs = (C.c_void_p * self.nstreams)(*[a.ctypes.data for a in keep])
+        # the library completes whatever was submitted before it runs this call: those results are ready for wait()
+        self._done = getattr(self, "_done", []) + getattr(self, "_tickets", [])
+        self._tickets = []
         n = nbatches * WAVE_BATCH
         wo = np.zeros((self.nstreams, self.nch, n + AGC_EXTRA), np.float32)
         axc = np.zeros((self.nstreams, self.nch, nbatches), np.uint8)
@@ -349,6 +352,23 @@ class Demod:
         a, b = C.c_int(0), C.c_int(0)
         _check(lib().mi_demod_last_path(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def process_planes(self, mag, nbatches, cplx=None, want_iq=False):
+        """mi_demod_process_planes (test entry): stage 2 over caller-supplied planes.  mag: [rows][count] float32; cplx:
+        [iq rows][count][2] or None.  Returns (waveout [nstreams][nch][n + AGC_EXTRA], axc, iq_out or None, stats)."""
+        n = nbatches * WAVE_BATCH
+        mag = np.ascontiguousarray(mag, dtype=np.float32)
+        wo = np.zeros((self.nstreams, self.nch, n + AGC_EXTRA), np.float32)
+        axc = np.zeros((self.nstreams, self.nch, nbatches), np.uint8)
+        iqo = np.zeros((self.nstreams, self.nch, n, 2), np.float32) if want_iq else None
+        stats = (ChannelStats * (self.nstreams * self.nch))()
+        zc = None if cplx is None else np.ascontiguousarray(cplx, dtype=np.float32)
+        f = lib().mi_demod_process_planes
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(f(self._h, mag.ctypes.data_as(C.c_void_p), None if zc is None else zc.ctypes.data_as(C.c_void_p), nbatches,
+                 wo.ctypes.data_as(C.c_void_p), None if iqo is None else iqo.ctypes.data_as(C.c_void_p), axc.ctypes.data_as(C.c_void_p),
+                 C.cast(stats, C.c_void_p)))
+        return wo, axc, iqo, list(stats)
 
     def prepare(self, host_slots=1):
         """mi_demod_prepare: stage-1 kernel of the plan + the staging of `host_slots` host-buffer calls, before the first batch."""

@@ -201,6 +201,7 @@ hipError_t launch_tp_audio_head(const TpArgs& a, hipStream_t s);                
 hipError_t launch_tp_core(const TpArgs& a, hipStream_t s);                         // k_tp_core
 hipError_t launch_tp_seg(const TpArgs& a, hipStream_t s);                          // k_tp_seg (needs core(i) only)
 hipError_t launch_tp_rest(const TpArgs& a, hipStream_t s, hipEvent_t* marks);      // k_tp_scan ... k_tp_finish (needs seg(i) and rest(i-1))
+hipError_t launch_row_max(const float* x, size_t stride, uint32_t n, int rows, unsigned* xmax, hipStream_t s);  // xmax[row] |= max of x[row][0..n)
 constexpr int TP_REST_MARKS = 3;  // marks (optional): after scan#0, after fix#0, after finish
 
 

@@ -187,6 +187,10 @@ struct mi_demod {
     int* d_rec[kSets] = {};  // per scratch set: the segment passes of the next call write theirs while this call's tail reads its own
     const float* prev_out_lo = nullptr;  // audio buffer of the previous call (its tail may still be writing it)
     const float* prev_out_hi = nullptr;
+    // mi_demod_process_planes (test entry): stage 1 is replaced by a copy of caller-supplied planes, [row][inject_count]
+    const float* inject_mag = nullptr;
+    const float2* inject_cplx = nullptr;
+    size_t inject_count = 0;
     const float* set_out_lo[kSets] = {};  // ... and of the time-parallel calls that used each scratch set last
     const float* set_out_hi[kSets] = {};
     int* d_tstart = nullptr;
@@ -406,6 +410,20 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         }
         return MI_OK;
     };
+    // stage 1 of the windows [f0, f0 + cc.nfft) of this call -- or, for mi_demod_process_planes, the caller's planes in their place
+    auto stage1_launch = [&](const mi::ChannelizeArgs& cc, uint32_t f0, hipStream_t st) -> hipError_t {
+        if (!h->inject_mag)
+            return mi::launch_channelize(cc, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, st);
+        hipError_t e = hipMemcpy2DAsync(cc.mag + cc.plane_off, cc.plane_stride * 4, h->inject_mag + f0, h->inject_count * 4, static_cast<size_t>(cc.nfft) * 4,
+                                        static_cast<size_t>(h->rows), hipMemcpyDeviceToDevice, st);
+        const size_t zrows = static_cast<size_t>(h->nstreams) * h->plan.n_iq_rows;
+        if (e == hipSuccess && zrows && h->inject_cplx)
+            e = hipMemcpy2DAsync(cc.cplx + cc.plane_off, cc.plane_stride * 8, h->inject_cplx + f0, h->inject_count * 8, static_cast<size_t>(cc.nfft) * 8, zrows,
+                                 hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess && cc.xmax)
+            e = mi::launch_row_max(cc.mag + cc.plane_off, cc.plane_stride, cc.nfft, h->rows, cc.xmax, st);
+        return e;
+    };
     hipEvent_t* evc = h->ev[h->cur];  // (the time-parallel and the pipelined serial branch switch to the next set)
     bool pipelined_serial = false;
     if (use_tp) {
@@ -557,7 +575,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             cc.plane_off = ca.plane_off + f0;
             cc.mag = planes;
             cc.xmax = h->d_xmax[q];
-            return mi::launch_channelize(cc, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, fs);
+            return stage1_launch(cc, f0, fs);
         };
         auto ev = [&](int i, int k) { return cev[static_cast<size_t>(i) * mi_demod::kEvPerChunk + k]; };
         HIP_TRY(hipEventRecord(h->ev_entry, s));
@@ -721,7 +739,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ca.mag = h->d_mag_set[p];
         ca.cplx = h->d_cplx_set[p];
         HIP_TRY(hipEventRecord(evc[0], fs));
-        HIP_TRY(mi::launch_channelize(ca, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, fs));
+        HIP_TRY(stage1_launch(ca, 0, fs));
         HIP_TRY(hipEventRecord(evc[1], fs));
         HIP_TRY(hipStreamWaitEvent(s, evc[1], 0));
         da.mag = h->d_mag_set[p];
@@ -748,7 +766,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         h->chain_live = false;  // k_demod does not maintain the time-parallel chain state
         h->serial_pipe = false;
         HIP_TRY(hipEventRecord(evc[0], s));
-        HIP_TRY(mi::launch_channelize(ca, h->plan.log2n, h->plan.dev.sfmt, h->nstreams, s));
+        HIP_TRY(stage1_launch(ca, 0, s));
         HIP_TRY(hipEventRecord(evc[1], s));
         HIP_TRY(mi::launch_demod(da, s));
     }
@@ -1387,6 +1405,66 @@ int mi_demod_process(mi_demod* h, const uint8_t* const* iq, int nbatches, float*
     if (rc != MI_OK)
         return rc;
     return slot_collect(h, 0);
+}
+
+int mi_demod_process_planes(mi_demod* h, const float* mag, const float* cplx, int nbatches, float* waveout, float* iq_out, char* axc, mi_channel_stats* stats) {
+    if (!h || !mag || !waveout || !axc)
+        return fail(MI_ERR_INVALID, "NULL argument");
+    if (nbatches < 1 || nbatches > h->max_batches)
+        return fail(MI_ERR_INVALID, "nbatches out of range for this handle");
+    if (h->plan.any_afc)
+        return fail(MI_ERR_UNSUPPORTED, "AFC channels read the spectrum of stage 1: no plane entry for them");
+    if (h->in_flight)
+        return fail(MI_ERR_INVALID, "submitted calls are in flight");
+    const size_t zrows = static_cast<size_t>(h->nstreams) * h->plan.n_iq_rows;
+    if (zrows && !cplx)
+        return fail(MI_ERR_INVALID, "this plan has raw-I/Q rows: cplx planes are needed");
+    HIP_TRY(hipSetDevice(h->gpu));
+    const size_t rows = static_cast<size_t>(h->rows), count = static_cast<size_t>(n_fft_for(h, nbatches));
+    const size_t nsteps = static_cast<size_t>(nbatches) * mi::kWaveBatch, wlen = nsteps + mi::kAgcExtra;
+    float *d_m = nullptr, *d_wo = nullptr;
+    float2 *d_z = nullptr, *d_io = nullptr;
+    char* d_ax = nullptr;
+    hipError_t e = dalloc(&d_m, rows * count);
+    if (e == hipSuccess && zrows)
+        e = dalloc(&d_z, zrows * count);
+    if (e == hipSuccess)
+        e = dalloc(&d_wo, rows * wlen);
+    if (e == hipSuccess && iq_out)
+        e = dalloc(&d_io, rows * nsteps);
+    if (e == hipSuccess)
+        e = dalloc(&d_ax, rows * static_cast<size_t>(nbatches));
+    if (e == hipSuccess)
+        e = hipMemcpy(d_m, mag, rows * count * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && zrows)
+        e = hipMemcpy(d_z, cplx, zrows * count * 8, hipMemcpyHostToDevice);
+    int rc = MI_OK;
+    if (e == hipSuccess) {
+        h->inject_mag = d_m, h->inject_cplx = d_z, h->inject_count = count;
+        // (the IQ pointer is never read: stage 1 is the copy above; the audio goes to [row][wlen] like the host entry's)
+        rc = enqueue(h, reinterpret_cast<const unsigned char*>(d_m), 0, 0, nbatches, d_wo, wlen, d_io, nsteps, d_ax, h->own_stream);
+        h->inject_mag = nullptr, h->inject_cplx = nullptr, h->inject_count = 0;
+        if (rc == MI_OK)
+            e = hipDeviceSynchronize();
+    }
+    if (rc == MI_OK && e == hipSuccess)
+        e = hipMemcpy2D(waveout, wlen * 4, d_wo, wlen * 4, nsteps * 4, rows, hipMemcpyDeviceToHost);
+    if (rc == MI_OK && e == hipSuccess)  // the lookahead: what the handle carries to the next call
+        e = hipMemcpy2D(waveout + nsteps, wlen * 4, h->d_carry, mi::kAgcExtra * 4, mi::kAgcExtra * 4, rows, hipMemcpyDeviceToHost);
+    if (rc == MI_OK && e == hipSuccess && iq_out)
+        e = hipMemcpy(iq_out, d_io, rows * nsteps * 8, hipMemcpyDeviceToHost);
+    if (rc == MI_OK && e == hipSuccess)
+        e = hipMemcpy(axc, d_ax, rows * static_cast<size_t>(nbatches), hipMemcpyDeviceToHost);
+    if (rc == MI_OK && e == hipSuccess && stats)
+        e = hipMemcpy(stats, h->d_stats, rows * sizeof(mi_channel_stats), hipMemcpyDeviceToHost);
+    void* tmp[] = {d_m, d_z, d_wo, d_io, d_ax};
+    for (void* q : tmp)
+        if (q)
+            (void)hipFree(q);
+    if (rc != MI_OK)
+        return rc;
+    HIP_TRY(e);
+    return MI_OK;
 }
 
 int mi_demod_get_stats(mi_demod* h, mi_channel_stats* stats) {

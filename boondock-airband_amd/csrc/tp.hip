@@ -2071,7 +2071,27 @@ __global__ void k_tp_audio_head(const TpArgs a) {
     a.wmain[static_cast<size_t>(row) * a.wmain_stride + v] = a.carry_prev[static_cast<size_t>(row) * kAgcExtra + v];
 }
 
+// xmax[row] = max(xmax[row], largest of x[row][0 .. n)) on the bit patterns (the values are >= 0): what stage 1 leaves for k_tp_full when
+// the planes come from somewhere else (mi_demod_process_planes)
+__global__ __launch_bounds__(256) void k_row_max(const float* __restrict__ x, const size_t stride, const uint32_t n, unsigned* __restrict__ xmax) {
+    const float* __restrict__ row = x + static_cast<size_t>(blockIdx.x) * stride;
+    float m = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += 256)
+        m = fmaxf(m, row[i]);
+    for (int o = 32; o > 0; o >>= 1)
+        m = fmaxf(m, __shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(&xmax[blockIdx.x], __float_as_uint(m));
+}
+
 }  // namespace
+
+hipError_t launch_row_max(const float* x, size_t stride, uint32_t n, int rows, unsigned* xmax, hipStream_t s) {
+    if (rows <= 0 || n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_row_max, dim3(rows), dim3(256), 0, s, x, stride, n, xmax);
+    return hipGetLastError();
+}
 
 #define TP_LAUNCH(kern, grid, block)                              \
     do {                                                          \

@@ -188,6 +188,19 @@ int mi_demod_last_path(mi_demod* h, int* time_parallel, int* unverified_rows);
 enum { MI_STAGE1_EXCHANGE_FULL = 0, MI_STAGE1_EXCHANGE_PRUNED = 1, MI_STAGE1_LANE_FULL = 2, MI_STAGE1_LANE_PLAN = 3 };
 int mi_demod_last_stage1(mi_demod* h, int* kind);
 
+/* TEST ENTRY -- stage 2 alone over caller-supplied planes: the per-channel loop of demodulate() (rtl_airband.cpp:517-669 with Squelch,
+ * CTCSS, filters) run by the same kernels and along the same paths as mi_demod_process (serial / time-parallel by nbatches),
+ * with stage 1 (convert x window -> FFT -> bin pick) replaced by a copy.  It exists so that the reference's own vectors for this
+ * part of the path (tests/golden/components_ref.npz: outputs of the reference's squelch.cpp / filters.cpp compiled unmodified) can
+ * be fed to the HIP code directly; a host never needs it.
+ *   mag   [nstreams*nch][count] the values channel_t.wavein would receive from the FFT, count = nbatches*WAVE_BATCH (+ AGC_EXTRA on the
+ *         handle's first call, as waveend starts at 0): entry AGC_EXTRA + i of the handle's running sequence is the squelch's raw
+ *         sample of step i (rtl_airband.cpp:529), entry i the AM audio sample (:580)
+ *   cplx  [nstreams*n_iq_rows][count][2] fftout of the channels with needs_raw_iq, in channel order (NULL if the plan has none)
+ *   waveout / iq_out / axc / stats  exactly as mi_demod_process.  Synchronous.  Not for AFC plans (MI_ERR_UNSUPPORTED). */
+int mi_demod_process_planes(mi_demod* h, const float* mag, const float* cplx, int nbatches, float* waveout, float* iq_out, char* axc,
+                            mi_channel_stats* stats);
+
 /* Diagnostics of the time-parallel path after a call that took it (synchronises): the exact Squelch core
  * state {noise_floor_, moving_avg_cap_, pre_filter_.capped_, pre_filter_.full_} before each segment (512 .. 4096 steps, by row count)
  * (core4: [nseg+1][4]) and diag8[0..3] = segments not accepted in verification scans 0..3 (scan 3 runs after the
