@@ -101,7 +101,7 @@ ABI_SYMBOLS = [
     "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_process_planes", "mi_demod_last_path", "mi_demod_last_stage1", "mi_demod_tp_debug", "mi_demod_kernel_time", "mi_demod_kernel_time_prev", "mi_demod_event_ms", "mi_demod_set_option", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
     "mi_plan_window", "mi_plan_twiddles", "mi_plan_levels", "mi_plan_sincos_lut", "mi_plan_channel", "mi_plan_ctcss_coeffs",
     "mi_iqgen_host", "mi_iqgen_device", "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_is_stereo", "mi_mixer_process_device",
-    "mi_gather_unique_id", "mi_gather_create", "mi_gather_destroy", "mi_gather_audio", "mi_gather_stream_wait", "mi_gather_sync",
+    "mi_gather_unique_id", "mi_gather_loopback_id", "mi_gather_create", "mi_gather_destroy", "mi_gather_audio", "mi_gather_stream_wait", "mi_gather_sync",
 ]
 
 _lib = None
@@ -478,6 +478,15 @@ class Gather:
     def unique_id():
         buf = (C.c_char * 128)()
         _check(lib().mi_gather_unique_id(C.byref(buf)))
+        return bytes(buf)
+
+    @staticmethod
+    def loopback_id(job):
+        """mi_gather_loopback_id (test transport): ranks of job `job` are threads of this process."""
+        buf = (C.c_char * 128)()
+        f = lib().mi_gather_loopback_id
+        f.argtypes = [C.c_void_p, C.c_uint64]
+        _check(f(C.byref(buf), job))
         return bytes(buf)
 
     def __init__(self, uid, rank, world, gpu, streams_per_rank, nch, max_batches):

@@ -14,7 +14,13 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -89,6 +95,147 @@ int nccl_fail(int rc, const char* where) {
             return gfail(MI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
+// ---- the transport under the gather: point-to-point send / recv in groups, RCCL's semantics ----
+// Two implementations: RCCL over xGMI (what a multi-GPU job runs), and a loopback between threads of ONE process on one GPU, which
+// lets a single-GPU box drive every world > 1 branch of mi_gather_audio -- the grouped transfers, the two-phase open-only protocol,
+// uneven and empty ranks -- with the same call sequence (tests/test_gather_c_abi.py).  The loopback is a test transport: a send
+// blocks its host thread until the peer has posted the matching recv (RCCL would queue it), which the gather's call order allows.
+struct Transport {
+    virtual ~Transport() {}
+    virtual int send(const void* buf, size_t count, int type, int peer, hipStream_t s) = 0;
+    virtual int recv(void* buf, size_t count, int type, int peer, hipStream_t s) = 0;
+    virtual int group_start() = 0;
+    virtual int group_end() = 0;
+};
+
+struct RcclTransport : Transport {
+    void* comm = nullptr;
+    ~RcclTransport() override {
+        if (comm && rccl().ok)
+            (void)rccl().comm_destroy(comm);
+    }
+    int send(const void* buf, size_t count, int type, int peer, hipStream_t s) override {
+        const int rc = rccl().send(buf, count, type, peer, comm, s);
+        return rc ? nccl_fail(rc, "ncclSend") : MI_OK;
+    }
+    int recv(void* buf, size_t count, int type, int peer, hipStream_t s) override {
+        const int rc = rccl().recv(buf, count, type, peer, comm, s);
+        return rc ? nccl_fail(rc, "ncclRecv") : MI_OK;
+    }
+    int group_start() override {
+        const int rc = rccl().group_start();
+        return rc ? nccl_fail(rc, "ncclGroupStart") : MI_OK;
+    }
+    int group_end() override {
+        const int rc = rccl().group_end();
+        return rc ? nccl_fail(rc, "ncclGroupEnd") : MI_OK;
+    }
+};
+
+constexpr char kLoopMagic[8] = {'M', 'I', 'L', 'O', 'O', 'P', '0', '1'};
+struct LoopMsg {
+    const void* src = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ready = nullptr;  // recorded on the sender's stream: the data is there
+    hipEvent_t done = nullptr;   // recorded on the receiver's stream: the copy has been made
+    bool taken = false, failed = false;
+};
+struct LoopHub {  // one per loopback id: the mailboxes (src rank, dst rank) of a job whose ranks are threads
+    std::mutex mu;
+    std::condition_variable cv;
+    std::map<std::pair<int, int>, std::deque<LoopMsg*>> box;
+};
+std::mutex g_hub_mu;
+std::map<uint64_t, std::shared_ptr<LoopHub>> g_hubs;
+
+struct LoopTransport : Transport {
+    std::shared_ptr<LoopHub> hub;
+    int rank = 0;
+    static size_t bytes_of(size_t count, int type) { return count * (type == kNcclFloat ? sizeof(float) : 1); }
+    int send(const void* buf, size_t count, int type, int peer, hipStream_t s) override {
+        LoopMsg m;
+        m.src = buf, m.bytes = bytes_of(count, type);
+        if (hipEventCreateWithFlags(&m.ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m.done, hipEventDisableTiming) != hipSuccess ||
+            hipEventRecord(m.ready, s) != hipSuccess)
+            return gfail(MI_ERR_HIP, "loopback send: event");
+        std::unique_lock<std::mutex> lk(hub->mu);
+        hub->box[{rank, peer}].push_back(&m);
+        hub->cv.notify_all();
+        const bool ok = hub->cv.wait_for(lk, std::chrono::seconds(60), [&] { return m.taken; });
+        if (!ok) {  // nobody came for it: take it back
+            auto& q = hub->box[{rank, peer}];
+            for (auto it = q.begin(); it != q.end(); ++it)
+                if (*it == &m) {
+                    q.erase(it);
+                    break;
+                }
+        }
+        lk.unlock();
+        // the buffer may be reused by whatever the sender enqueues next: behind the receiver's copy
+        hipError_t e = (ok && !m.failed) ? hipStreamWaitEvent(s, m.done, 0) : hipSuccess;
+        (void)hipEventDestroy(m.ready);
+        if (ok)
+            (void)hipEventSynchronize(m.done);  // (the event object dies with this frame)
+        (void)hipEventDestroy(m.done);
+        if (!ok)
+            return gfail(MI_ERR_HIP, "loopback send: no matching recv within 60 s");
+        if (m.failed || e != hipSuccess)
+            return gfail(MI_ERR_HIP, "loopback send: the receiver's copy failed");
+        return MI_OK;
+    }
+    int recv(void* buf, size_t count, int type, int peer, hipStream_t s) override {
+        std::unique_lock<std::mutex> lk(hub->mu);
+        auto& q = hub->box[{peer, rank}];
+        if (!hub->cv.wait_for(lk, std::chrono::seconds(60), [&] { return !q.empty(); }))
+            return gfail(MI_ERR_HIP, "loopback recv: no matching send within 60 s");
+        LoopMsg* m = q.front();
+        q.pop_front();
+        hipError_t e = (m->bytes == bytes_of(count, type)) ? hipSuccess : hipErrorInvalidValue;  // RCCL would hang or corrupt: the test transport says so
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(s, m->ready, 0);
+        if (e == hipSuccess && m->bytes)
+            e = hipMemcpyAsync(buf, m->src, m->bytes, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess)
+            e = hipEventRecord(m->done, s);
+        m->failed = e != hipSuccess;
+        m->taken = true;
+        hub->cv.notify_all();
+        lk.unlock();
+        if (e != hipSuccess)
+            return gfail(MI_ERR_HIP, std::string("loopback recv: ") + (e == hipErrorInvalidValue ? "send / recv sizes differ" : hipGetErrorString(e)));
+        return MI_OK;
+    }
+    int group_start() override { return MI_OK; }
+    int group_end() override { return MI_OK; }
+};
+
+// every transfer of a step between group_start and group_end; an error in between still closes the group (RCCL keeps an open
+// group per thread: leaving it open would swallow the next step's calls)
+struct Group {
+    Transport* t;
+    bool open = false;
+    explicit Group(Transport* tt) : t(tt) {}
+    int start() {
+        const int rc = t->group_start();
+        open = rc == MI_OK;
+        return rc;
+    }
+    int end() {
+        open = false;
+        return t->group_end();
+    }
+    ~Group() {
+        if (open)
+            (void)t->group_end();
+    }
+};
+#define T_TRY(expr)             \
+    do {                        \
+        const int rc__ = (expr); \
+        if (rc__ != MI_OK)      \
+            return rc__;        \
+    } while (0)
+
 // blocks of WAVE_BATCH floats: dst block j = src block idx[j] (compaction on a sender), or dst block idx[j] = src block j
 // (scatter on rank 0); 500 lanes x float4 per block
 __global__ __launch_bounds__(256) void k_move_blocks(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ idx, int nblocks, int scatter) {
@@ -109,7 +256,7 @@ struct mi_gather {
     std::vector<int> streams;      // per rank
     std::vector<size_t> row_lo;    // first row (stream * nch + channel) of each rank in the job-wide arrays
     size_t rows_local = 0, rows_total = 0;
-    void* comm = nullptr;
+    std::unique_ptr<Transport> tr;  // null at world 1
     hipStream_t side = nullptr;
     hipEvent_t ev_in = nullptr, ev_done = nullptr;
     // open-batches-only mode
@@ -131,14 +278,22 @@ int mi_gather_unique_id(mi_gather_id* id) {
     return MI_OK;
 }
 
+int mi_gather_loopback_id(mi_gather_id* id, uint64_t job) {
+    if (!id)
+        return gfail(MI_ERR_INVALID, "NULL argument");
+    std::memset(id->internal, 0, sizeof(id->internal));
+    std::memcpy(id->internal, kLoopMagic, sizeof(kLoopMagic));
+    std::memcpy(id->internal + 8, &job, sizeof(job));
+    return MI_OK;
+}
+
 void mi_gather_destroy(mi_gather* g) {
     if (!g)
         return;
     (void)hipSetDevice(g->gpu);
     if (g->side)
         (void)hipStreamSynchronize(g->side);
-    if (g->comm && rccl().ok)
-        (void)rccl().comm_destroy(g->comm);
+    g->tr.reset();
     if (g->d_pack)
         (void)hipFree(g->d_pack);
     if (g->d_idx)
@@ -191,13 +346,28 @@ int mi_gather_create(const mi_gather_id* id, int rank, int world, int gpu, const
         e = hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming);
     if (e != hipSuccess)
         return bail(gfail(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? MI_ERR_NO_DEVICE : MI_ERR_HIP, std::string("mi_gather_create: ") + hipGetErrorString(e)));
-    if (world > 1) {
+    if (world > 1 && std::memcmp(id->internal, kLoopMagic, sizeof(kLoopMagic)) == 0) {
+        uint64_t key = 0;
+        std::memcpy(&key, id->internal + 8, sizeof(key));
+        auto t = std::make_unique<LoopTransport>();
+        t->rank = rank;
+        {
+            std::lock_guard<std::mutex> lk(g_hub_mu);
+            std::shared_ptr<LoopHub>& hub = g_hubs[key];
+            if (!hub)
+                hub = std::make_shared<LoopHub>();
+            t->hub = hub;
+        }
+        g->tr = std::move(t);
+    } else if (world > 1) {
         Rccl& r = rccl();
         if (!r.ok)
             return bail(gfail(MI_ERR_UNSUPPORTED, "RCCL (librccl.so.1) could not be loaded"));
-        const int rc = r.comm_init_rank(&g->comm, world, *id, rank);
+        auto t = std::make_unique<RcclTransport>();
+        const int rc = r.comm_init_rank(&t->comm, world, *id, rank);
         if (rc != 0)
             return bail(nccl_fail(rc, "ncclCommInitRank"));
+        g->tr = std::move(t);
     }
     *out = g;
     return MI_OK;
@@ -208,7 +378,7 @@ int mi_gather_audio(mi_gather* g, const float* d_waveout, const char* d_axc, int
     if (!g || nbatches < 1 || nbatches > g->max_batches || (g->rows_local && (!d_waveout || !d_axc)) || (g->rank == 0 && (!d_all_waveout || !d_all_axc)))
         return gfail(MI_ERR_INVALID, "bad argument");
     G_HIP_TRY(hipSetDevice(g->gpu));
-    Rccl& r = rccl();
+    Transport* const t = g->tr.get();
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const size_t n = static_cast<size_t>(nbatches) * mi::kWaveBatch;
     const size_t nb = static_cast<size_t>(nbatches);
@@ -223,31 +393,46 @@ int mi_gather_audio(mi_gather* g, const float* d_waveout, const char* d_axc, int
                 G_HIP_TRY(hipMemcpyAsync(d_all_axc + g->row_lo[0] * nb, d_axc, g->rows_local * nb, hipMemcpyDeviceToDevice, q));
             }
             if (g->world > 1) {
-                NCCL_TRY(r.group_start());
+                Group grp(t);
+                T_TRY(grp.start());
                 for (int p = 1; p < g->world; ++p) {
                     const size_t rows = static_cast<size_t>(g->streams[p]) * g->nch;
                     if (!rows)
                         continue;
-                    NCCL_TRY(r.recv(d_all_axc + g->row_lo[p] * nb, rows * nb, kNcclChar, p, g->comm, q));
-                    NCCL_TRY(r.recv(d_all_waveout + g->row_lo[p] * n, rows * n, kNcclFloat, p, g->comm, q));
+                    T_TRY(t->recv(d_all_axc + g->row_lo[p] * nb, rows * nb, kNcclChar, p, q));
+                    T_TRY(t->recv(d_all_waveout + g->row_lo[p] * n, rows * n, kNcclFloat, p, q));
                 }
-                NCCL_TRY(r.group_end());
+                T_TRY(grp.end());
             }
         } else if (g->rows_local) {
-            NCCL_TRY(r.group_start());
-            NCCL_TRY(r.send(d_axc, g->rows_local * nb, kNcclChar, 0, g->comm, q));
-            NCCL_TRY(r.send(d_waveout, g->rows_local * n, kNcclFloat, 0, g->comm, q));
-            NCCL_TRY(r.group_end());
+            Group grp(t);
+            T_TRY(grp.start());
+            T_TRY(t->send(d_axc, g->rows_local * nb, kNcclChar, 0, q));
+            T_TRY(t->send(d_waveout, g->rows_local * n, kNcclFloat, 0, q));
+            T_TRY(grp.end());
         }
         G_HIP_TRY(hipEventRecord(g->ev_done, q));
         return MI_OK;
     }
     // ---- open batches only ----
     const size_t max_blocks = (g->rank == 0 ? g->rows_total : g->rows_local) * static_cast<size_t>(g->max_batches);
-    if (!g->d_pack && max_blocks) {
-        G_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->d_pack), max_blocks * mi::kWaveBatch * sizeof(float)));
-        G_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->d_idx), max_blocks * sizeof(int)));
-        G_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g->h_flags), max_blocks, hipHostMallocDefault));
+    if (!g->d_pack && max_blocks) {  // all three or none: a half-allocated scratch must not reach the kernels below
+        float* pack = nullptr;
+        int* idx = nullptr;
+        char* flags = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&pack), max_blocks * mi::kWaveBatch * sizeof(float));
+        if (e == hipSuccess)
+            e = hipMalloc(reinterpret_cast<void**>(&idx), max_blocks * sizeof(int));
+        if (e == hipSuccess)
+            e = hipHostMalloc(reinterpret_cast<void**>(&flags), max_blocks, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            if (pack)
+                (void)hipFree(pack);
+            if (idx)
+                (void)hipFree(idx);
+            return gfail(MI_ERR_NOMEM, std::string("mi_gather_audio: scratch of the open-batches mode: ") + hipGetErrorString(e));
+        }
+        g->d_pack = pack, g->d_idx = idx, g->h_flags = flags;
     }
     auto open_blocks = [&](const char* flags, size_t count, size_t base) {  // indices (relative to `base`) of the blocks that carry a signal
         for (size_t i = 0; i < count; ++i)
@@ -259,9 +444,12 @@ int mi_gather_audio(mi_gather* g, const float* d_waveout, const char* d_axc, int
             return MI_OK;
         const size_t blocks = g->rows_local * nb;
         G_HIP_TRY(hipMemcpyAsync(g->h_flags, d_axc, blocks, hipMemcpyDeviceToHost, q));
-        NCCL_TRY(r.group_start());
-        NCCL_TRY(r.send(d_axc, blocks, kNcclChar, 0, g->comm, q));
-        NCCL_TRY(r.group_end());
+        {
+            Group grp(t);
+            T_TRY(grp.start());
+            T_TRY(t->send(d_axc, blocks, kNcclChar, 0, q));
+            T_TRY(grp.end());
+        }
         G_HIP_TRY(hipStreamSynchronize(q));
         g->idx_host.clear();
         open_blocks(g->h_flags, blocks, 0);
@@ -270,9 +458,10 @@ int mi_gather_audio(mi_gather* g, const float* d_waveout, const char* d_axc, int
             G_HIP_TRY(hipMemcpyAsync(g->d_idx, g->idx_host.data(), k * sizeof(int), hipMemcpyHostToDevice, q));
             hipLaunchKernelGGL(k_move_blocks, dim3(static_cast<unsigned>(k)), dim3(256), 0, q, d_waveout, g->d_pack, g->d_idx, static_cast<int>(k), 0);
             G_HIP_TRY(hipGetLastError());
-            NCCL_TRY(r.group_start());
-            NCCL_TRY(r.send(g->d_pack, k * mi::kWaveBatch, kNcclFloat, 0, g->comm, q));
-            NCCL_TRY(r.group_end());
+            Group grp(t);
+            T_TRY(grp.start());
+            T_TRY(t->send(g->d_pack, k * mi::kWaveBatch, kNcclFloat, 0, q));
+            T_TRY(grp.end());
         }
         G_HIP_TRY(hipEventRecord(g->ev_done, q));
         return MI_OK;
@@ -281,13 +470,14 @@ int mi_gather_audio(mi_gather* g, const float* d_waveout, const char* d_axc, int
     if (g->rows_local)
         G_HIP_TRY(hipMemcpyAsync(d_all_axc + g->row_lo[0] * nb, d_axc, g->rows_local * nb, hipMemcpyDeviceToDevice, q));
     if (g->world > 1) {
-        NCCL_TRY(r.group_start());
+        Group grp(t);
+        T_TRY(grp.start());
         for (int p = 1; p < g->world; ++p) {
             const size_t rows = static_cast<size_t>(g->streams[p]) * g->nch;
             if (rows)
-                NCCL_TRY(r.recv(d_all_axc + g->row_lo[p] * nb, rows * nb, kNcclChar, p, g->comm, q));
+                T_TRY(t->recv(d_all_axc + g->row_lo[p] * nb, rows * nb, kNcclChar, p, q));
         }
-        NCCL_TRY(r.group_end());
+        T_TRY(grp.end());
     }
     G_HIP_TRY(hipMemcpyAsync(g->h_flags, d_all_axc, g->rows_total * nb, hipMemcpyDeviceToHost, q));
     G_HIP_TRY(hipMemsetAsync(d_all_waveout, 0, g->rows_total * n * sizeof(float), q));
@@ -308,13 +498,14 @@ int mi_gather_audio(mi_gather* g, const float* d_waveout, const char* d_axc, int
             G_HIP_TRY(hipGetLastError());
         }
         if (g->world > 1) {
-            NCCL_TRY(r.group_start());
+            Group grp(t);
+            T_TRY(grp.start());
             for (int p = 1; p < g->world; ++p) {
                 const size_t cnt = first[static_cast<size_t>(p) + 1] - first[static_cast<size_t>(p)];
                 if (cnt)
-                    NCCL_TRY(r.recv(g->d_pack + first[static_cast<size_t>(p)] * mi::kWaveBatch, cnt * mi::kWaveBatch, kNcclFloat, p, g->comm, q));
+                    T_TRY(t->recv(g->d_pack + first[static_cast<size_t>(p)] * mi::kWaveBatch, cnt * mi::kWaveBatch, kNcclFloat, p, q));
             }
-            NCCL_TRY(r.group_end());
+            T_TRY(grp.end());
         }
         hipLaunchKernelGGL(k_move_blocks, dim3(static_cast<unsigned>(k)), dim3(256), 0, q, g->d_pack, d_all_waveout, g->d_idx, static_cast<int>(k), 1);
         G_HIP_TRY(hipGetLastError());

@@ -364,6 +364,10 @@ int mi_mixer_process_device(mi_mixer* m, const float* d_waveout, size_t row_stri
 typedef struct { char internal[128]; } mi_gather_id;
 typedef struct mi_gather mi_gather;
 int mi_gather_unique_id(mi_gather_id* id);
+/* TEST TRANSPORT: an id that makes mi_gather_create connect the ranks of job number `job` through an in-process loopback (one host
+ * thread per rank, any GPU -- all on the same one is fine) instead of RCCL: device-to-device copies ordered by events, same
+ * send / recv / group call sequence.  It lets a single-GPU machine execute every world > 1 branch of mi_gather_audio. */
+int mi_gather_loopback_id(mi_gather_id* id, uint64_t job);
 int mi_gather_create(const mi_gather_id* id, int rank, int world, int gpu, const int* streams_per_rank, int nch, int max_batches, mi_gather** out);
 void mi_gather_destroy(mi_gather* g);
 int mi_gather_audio(mi_gather* g, const float* d_waveout, const char* d_axc, int nbatches, int open_only, float* d_all_waveout, char* d_all_axc,

@@ -1,7 +1,10 @@
 """mi_gather_* (include/mi_airband.h): the C-ABI gather of audio + flags to rank 0 over RCCL, for a C++ host.
-World size 1 runs on the one-GPU box (local copy, open-batches-only compaction / scatter kernels, stream hand-off); the
-two-rank test needs two GPUs and skips otherwise -- N > 1 host logic is also covered on CPU by tests/test_distributed_gloo.py
-through the Python twin (shard.AudioGather), which bench.py uses."""
+World size 1 runs on the one-GPU box (local copy, open-batches-only compaction / scatter kernels, stream hand-off).  Every world > 1
+branch -- grouped sends / receives, the two-phase open-batches-only protocol with its block counts and landing offsets, uneven and
+empty ranks -- runs there too, through the loopback transport (mi_gather_loopback_id: the ranks are threads of one process, the
+transfers device-to-device copies ordered by events, the call sequence RCCL's).  The RCCL transport itself (ncclCommInitRank with
+the id by value, ncclSend / ncclRecv) needs two GPUs: that test skips on the one-GPU box and is the only part left unpinned there.
+N > 1 host logic is also covered on CPU by tests/test_distributed_gloo.py through the Python twin (shard.AudioGather)."""
 import os
 import sys
 
@@ -41,6 +44,61 @@ def test_gather_world1_full_and_open_only(pkg, open_only):
         d_all.fill_(9.0)
     g.sync()
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("streams", [[3, 2], [2, 0, 3, 1], [0, 4, 1]])
+def test_gather_many_ranks_through_the_loopback_transport(pkg, streams):
+    """Ranks as threads on the one GPU: full and open-only gathers, two steps each, uneven and empty ranks (rank 0 included)."""
+    import threading
+    import torch
+    world, nch, nbat = len(streams), 3, 4
+    rng = np.random.default_rng(17 + world)
+    job = int(rng.integers(1, 1 << 40))
+    uid = pkg.Gather.loopback_id(job)
+    steps = [_fake_step(rng, sum(streams), nch, nbat) for _ in range(2)]
+    for _, fl in steps:
+        fl[:, :, :] = np.where(rng.random(fl.shape) < 0.4, ord("*"), ord(" "))
+    steps[1][1][sum(streams[:2]):sum(streams[:2]) + 1] = ord(" ")  # a rank-2 stream (if any) with nothing open in the second step
+    errors, results = [], {}
+
+    def run(rank):
+        try:
+            lo = sum(streams[:rank])
+            g = pkg.Gather(uid, rank, world, 0, streams, nch, nbat)
+            st = torch.cuda.Stream()
+            for open_only in (False, True):
+                for k, (audio, flags) in enumerate(steps):
+                    mine_a = torch.from_numpy(np.ascontiguousarray(audio[lo:lo + streams[rank]])).cuda()
+                    mine_f = torch.from_numpy(np.ascontiguousarray(flags[lo:lo + streams[rank]])).cuda()
+                    d_all = torch.full((sum(streams), nch, nbat * WAVE_BATCH), 5.0, dtype=torch.float32, device="cuda") if rank == 0 else None
+                    d_allf = torch.zeros((sum(streams), nch, nbat), dtype=torch.uint8, device="cuda") if rank == 0 else None
+                    torch.cuda.synchronize()
+                    g.audio(mine_a.data_ptr() if streams[rank] else None, mine_f.data_ptr() if streams[rank] else None, nbat,
+                            None if d_all is None else d_all.data_ptr(), None if d_allf is None else d_allf.data_ptr(), open_only=open_only,
+                            hip_stream=st.cuda_stream)
+                    g.stream_wait(st.cuda_stream)
+                    g.sync()
+                    st.synchronize()
+                    if rank == 0:
+                        results[(open_only, k)] = (d_all.cpu().numpy(), d_allf.cpu().numpy())
+            g.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=180)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads)
+    for open_only in (False, True):
+        for k, (audio, flags) in enumerate(steps):
+            got_a, got_f = results[(open_only, k)]
+            want = audio if not open_only else np.where(np.repeat(flags != ord(" "), WAVE_BATCH, axis=2), audio, 0.0).astype(np.float32)
+            assert np.array_equal(got_f, flags), (open_only, k)
+            assert np.array_equal(got_a, want), (open_only, k)
 
 
 def _rank(rank, world, tmp):
