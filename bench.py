@@ -262,8 +262,18 @@ def roofline_block(res, kernels, traffic, traffic_src):
     achieved = launch_samples * path_bytes_per_sample / (k["ms"] * 1e-3) / 1e9
     path_gbs = sps * path_bytes_per_sample / step_s / 1e9
     tflops = sps * flop_per_sample / step_s / 1e12
+    limited_by = {"k_tp_core": "latency: the serial squelch core chain, one workgroup per channel (dependent VALU issue, not bytes)",
+                  "k_channelize": "fp32 VALU / LDS issue of stage 1 (65 flop/B at fft 512: far right of the HBM ridge)",
+                  "k_demod": "VALU issue of one wave per channel (the serial per-channel loop)",
+                  "k_tp_seg": "lane latency of the segment pass", "k_tp_full": "lane latency of the aggregate pass"}.get(dom.split("#")[0], "launch latency of the tail passes")
+    sum_ms = sum(v["ms_per_step"] for v in kernels.values())
     return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic_of(traffic, dom), "traffic_source": traffic_src,
+            # `bound` names the roofline the contract prices against; what actually limits the step:
+            "limited_by": limited_by,
+            "critical_path_ms": k["ms_per_step"],            # the dominant kernel's time per step: the step cannot be shorter
+            "sum_of_kernel_ms_per_step": sum_ms,             # > ms_per_step because consecutive steps overlap on several streams
+            "overlap_factor": sum_ms / res["ms_per_step"],
             "definition": "achieved = SURVEY 8(d) algorithmic bytes per sample (path_bytes_per_sample) x samples per launch / the dominant "
                           "kernel's mean launch duration (HIP events on its launch stream)",
             "path_bytes_per_sample": path_bytes_per_sample,

@@ -98,7 +98,7 @@ class MixInput(C.Structure):  # mi_mix_input
 ABI_SYMBOLS = [
     "mi_last_error", "mi_device_count", "mi_demod_create", "mi_demod_destroy", "mi_demod_prepare", "mi_set_cache_dir", "mi_jit_counts", "mi_demod_bytes_needed", "mi_demod_bytes_consumed",
     "mi_demod_hop_bytes", "mi_demod_process", "mi_demod_submit", "mi_demod_wait", "mi_host_alloc", "mi_host_free", "mi_demod_process_device", "mi_demod_get_stats", "mi_demod_state_size",
-    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_process_planes", "mi_demod_last_path", "mi_demod_last_stage1", "mi_demod_tp_debug", "mi_demod_kernel_time", "mi_demod_kernel_time_prev", "mi_demod_event_ms", "mi_demod_set_option", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
+    "mi_demod_get_state", "mi_demod_set_state", "mi_demod_read_planes", "mi_demod_process_planes", "mi_demod_last_path", "mi_demod_last_stage1", "mi_demod_pre_wave_timeouts", "mi_demod_tp_debug", "mi_demod_kernel_time", "mi_demod_kernel_time_prev", "mi_demod_event_ms", "mi_demod_set_option", "mi_demod_last_kernel_ms", "mi_plan_create", "mi_plan_destroy", "mi_plan_fft_size",
     "mi_plan_window", "mi_plan_twiddles", "mi_plan_levels", "mi_plan_sincos_lut", "mi_plan_channel", "mi_plan_ctcss_coeffs",
     "mi_iqgen_host", "mi_iqgen_device", "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_is_stereo", "mi_mixer_process_device",
     "mi_gather_unique_id", "mi_gather_loopback_id", "mi_gather_create", "mi_gather_destroy", "mi_gather_audio", "mi_gather_stream_wait", "mi_gather_sync",
@@ -373,6 +373,13 @@ class Demod:
     def prepare(self, host_slots=1):
         """mi_demod_prepare: stage-1 kernel of the plan + the staging of `host_slots` host-buffer calls, before the first batch."""
         _check(lib().mi_demod_prepare(self._h, host_slots))
+
+    def pre_wave_timeouts(self):
+        n = C.c_uint(0)
+        f = lib().mi_demod_pre_wave_timeouts
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+        _check(f(self._h, C.byref(n)))
+        return n.value
 
     def last_stage1(self):
         """MI_STAGE1_* of the last call: 0 / 1 exchange kernels (full / pruned), 2 / 3 lane-resident (full graph / plan-compiled)."""

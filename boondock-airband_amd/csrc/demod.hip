@@ -484,7 +484,7 @@ struct BlockIo {
 //   CLOSING           as OPEN without the has_signal() test (it is only asked when the delay runs out)
 //   LOW_SIGNAL_ABORT  averages + noise floor only
 template <bool kPre>
-__device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo& io, const uint32_t i0_, const int kmax_, bool& batch_open, LdsPre* pre, const bool pre_on) {
+__device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo& io, const uint32_t i0_, const int kmax_, bool& batch_open, LdsPre* pre, bool& pre_on) {
     // wave-uniform by construction; say so, so that loop control stays on the scalar unit
     const uint32_t i0 = __builtin_amdgcn_readfirstlane(i0_);
     const int kmax = __builtin_amdgcn_readfirstlane(kmax_);
@@ -550,7 +550,14 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     if constexpr (kPre) {
         // the pre-filter wave has walked these steps (and many more): take its values
         // (`pre` is an LDS address and may well be 0: never tested, the flag says whether the pre-filter wave is there)
-        if (pre_on && pre_wait(pre, lane, i0, i0 + static_cast<uint32_t>(kmax))) {
+        // (a wait that runs out is final: from then on this wave computes its own values and never looks at the ring again -- on a
+        //  low-pass channel its blocks may since have overwritten magnitudes the late wave has yet to read, rtl_airband.cpp:548)
+        if (pre_on && !pre_wait(pre, lane, i0, i0 + static_cast<uint32_t>(kmax))) {
+            pre_on = false;
+            if (lane == 0 && a.pre_timeouts)
+                atomicAdd(a.pre_timeouts, 1u);
+        }
+        if (pre_on) {
             const unsigned at = (i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u);
             C = *(pre_vf32*)&pre->C[at], F = *(pre_vf32*)&pre->F[at], NFv = *(pre_vf32*)&pre->NF[at], CAPv = *(pre_vf32*)&pre->CAP[at];
             const int nb0 = __builtin_amdgcn_readfirstlane((15 - static_cast<int>(s.sample_count & 15u)) & 15);  // first step whose sample_count_ is a multiple of 16
@@ -999,8 +1006,11 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
                   // pre-filter wave, which reads the raw one.  Other channels only say where they are (the pre-filter wave stays
                   // within the ring's reach of that).
                   if (P.lowpass_enabled && zrow) {
-                      if (!pre_wait(pre, c.lane, i0, i0 + 4u))
+                      if (!pre_wait(pre, c.lane, i0, i0 + 4u)) {
                           pre_on = false;  // (it never came: this wave computes everything itself from here on)
+                          if (c.lane == 0 && a.pre_timeouts)
+                              atomicAdd(a.pre_timeouts, 1u);
+                      }
                   } else if (c.lane == 0) {
                       *(pre_vu32*)&pre->m_pos = i0;
                   }
@@ -1349,7 +1359,10 @@ __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const 
             const unsigned at = (i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u);
             *(pre_vf32*)&pre->C[at] = C, *(pre_vf32*)&pre->F[at] = F, *(pre_vf32*)&pre->NF[at] = NFv, *(pre_vf32*)&pre->CAP[at] = CAPv;
         }
-        asm volatile("" ::: "memory");
+        // The ring values before the mark.  A wave's LDS operations are issued and executed in order, so the compiler barrier is what
+        // matters; the wait makes the order explicit at the price of the LDS counter only (a workgroup fence would also wait for
+        // the global loads this wave has in flight for the next block: vmcnt(0) once per block).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0)
             *(pre_vu32*)&pre->h_done = i0 + static_cast<uint32_t>(kmax);
         // the state the next block starts from

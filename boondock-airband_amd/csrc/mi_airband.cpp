@@ -46,6 +46,17 @@ int hip_fail(hipError_t e, const char* where) {
         if (e__ != hipSuccess)             \
             return hip_fail(e__, #expr);   \
     } while (0)
+const char kFailedMsg[] = "an earlier call on this handle failed after its state had advanced: destroy it, or restore a checkpoint (mi_demod_set_state)";
+// ... after the DSP state of the handle has advanced (enqueue() succeeded): the results of this call are lost and the state cannot be
+// rolled back, so the handle is marked and refuses further calls (mi_demod_set_state with a checkpoint revives it)
+#define HIP_TRY_F(expr)                                                              \
+    do {                                                                             \
+        hipError_t e__ = (expr);                                                     \
+        if (e__ != hipSuccess) {                                                     \
+            h->failed = true;                                                        \
+            return hip_fail(e__, #expr);                                             \
+        }                                                                            \
+    } while (0)
 
 template <class T>
 hipError_t dalloc(T** p, size_t count) {
@@ -149,6 +160,7 @@ struct mi_demod {
     float* d_ctcss_coeff = nullptr;
     float* d_ctcss_q = nullptr;
     mi_channel_stats* d_stats = nullptr;
+    unsigned* d_pre_timeouts = nullptr;  // waits of a channel wave for its pre-filter wave that ran out (k_demod_pw): expected 0
     // staging for the host-buffer entries: three slots, so that one call can be uploaded and one downloaded while a third
     // computes (mi_demod_submit / mi_demod_wait; mi_demod_process uses slot 0 alone).  A time-parallel call has ~2.5 ms of
     // latency whatever its length (segment pass -> scan -> fix -> ...), so with two slots a 16-s call could not be fed faster
@@ -175,6 +187,7 @@ struct mi_demod {
     size_t iq_stride = 0, h_out_bytes = 0;
     bool slots_ready[kSlots] = {};
     int slot_next = 0, slot_oldest = 0, in_flight = 0;
+    bool failed = false;  // a call advanced the DSP state and then could not deliver its results: every further call is refused
     hipStream_t copy_stream = nullptr;  // uploads of submitted calls
     hipStream_t down_stream = nullptr;  // their downloads
     // time-parallel stage 2 (tp.hip): only when every channel is a plain AM channel
@@ -401,6 +414,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     // +12 %); with a thousand rows and more the machine is full and a second wave per row only takes LDS and issue slots from
     // stage 1 (32 streams: +-0, 64 streams: -27 %)
     da.pre_wave = (h->opt_pre_wave < 0 ? h->rows <= 512 : h->opt_pre_wave != 0) ? 1 : 0;
+    da.pre_timeouts = h->d_pre_timeouts;
 
     // the serial kernels expect the carried AGC_EXTRA samples of every row at the front of the planes they work on
     auto head_in_place = [&]() -> int {
@@ -799,7 +813,7 @@ void mi_demod_destroy(mi_demod* h) {
     (void)hipSetDevice(h->gpu);
     (void)hipDeviceSynchronize();  // calls may still be in flight on the handle's own streams
     void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_t1, h->d_prune_t2, h->d_prune_rank, h->d_l64_chan, h->d_l64_chan_full, h->d_l64_tickets, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx_set[0], h->d_cplx_set[1], h->d_carry_set[0], h->d_carry_set[1], h->d_carry_set[2], h->d_carry_set[3],
-                    h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats,
+                    h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_pre_timeouts,
                     h->d_rows,   h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_fullbound, h->d_afc_spec};
     for (void* p : ptrs)
         if (p)
@@ -938,6 +952,8 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     TRY_OR_BAIL(dalloc(&h->d_ctcss_coeff, p.ctcss_coeff.size()));
     TRY_OR_BAIL(dalloc(&h->d_ctcss_q, static_cast<size_t>(nstreams) * p.n_ctcss_rows * 4 * mi::kMaxTones));
     TRY_OR_BAIL(dalloc(&h->d_stats, rows));
+    TRY_OR_BAIL(dalloc(&h->d_pre_timeouts, 1));
+    TRY_OR_BAIL(hipMemset(h->d_pre_timeouts, 0, sizeof(unsigned)));
     TRY_OR_BAIL(hipMemcpy(h->d_window, p.window.data(), p.window.size() * 4, hipMemcpyHostToDevice));
     TRY_OR_BAIL(hipMemcpy(h->d_tw, p.tw.data(), p.tw.size() * 4, hipMemcpyHostToDevice));
     if (p.prune.enabled) {
@@ -1136,6 +1152,8 @@ int mi_demod_process_device(mi_demod* h, const void* d_iq, size_t stream_stride_
                             char* d_axc, void* hip_stream) {
     if (!h || !d_iq || !d_waveout || !d_axc)
         return fail(MI_ERR_INVALID, "NULL argument");
+    if (h->failed)
+        return fail(MI_ERR_HIP, kFailedMsg);
     if (nbatches < 1 || nbatches > h->max_batches)
         return fail(MI_ERR_INVALID, "nbatches out of range for this handle");
     const size_t align = 2 * static_cast<size_t>(h->plan.bytes_per_sample);
@@ -1269,31 +1287,31 @@ int slot_launch(mi_demod* h, int k, const uint8_t* const* iq, int nbatches, bool
     if (rc != MI_OK)
         return rc;
     // the lookahead and the statistics belong to the handle and move on with the next call: snapshot them behind this one
-    HIP_TRY(hipMemcpy2DAsync(sl.d_wout + nsteps, wstride * sizeof(float), h->d_carry, mi::kAgcExtra * sizeof(float), mi::kAgcExtra * sizeof(float), rows,
+    HIP_TRY_F(hipMemcpy2DAsync(sl.d_wout + nsteps, wstride * sizeof(float), h->d_carry, mi::kAgcExtra * sizeof(float), mi::kAgcExtra * sizeof(float), rows,
                              hipMemcpyDeviceToDevice, s));
     if (want_stats)
-        HIP_TRY(hipMemcpyAsync(sl.d_stats, h->d_stats, rows * sizeof(mi_channel_stats), hipMemcpyDeviceToDevice, s));
+        HIP_TRY_F(hipMemcpyAsync(sl.d_stats, h->d_stats, rows * sizeof(mi_channel_stats), hipMemcpyDeviceToDevice, s));
     hipStream_t down = s;
     if (pipelined) {
-        HIP_TRY(hipEventRecord(sl.done, s));
-        HIP_TRY(hipStreamWaitEvent(h->down_stream, sl.done, 0));
+        HIP_TRY_F(hipEventRecord(sl.done, s));
+        HIP_TRY_F(hipStreamWaitEvent(h->down_stream, sl.done, 0));
         down = h->down_stream;
     }
     const OutLayout o = out_layout(h, nbatches);
     sl.wave_direct = is_pinned(sl.waveout);
-    HIP_TRY(hipMemcpyAsync(sl.wave_direct ? reinterpret_cast<unsigned char*>(sl.waveout) : sl.h_out + o.wave, sl.d_wout, rows * wstride * sizeof(float),
+    HIP_TRY_F(hipMemcpyAsync(sl.wave_direct ? reinterpret_cast<unsigned char*>(sl.waveout) : sl.h_out + o.wave, sl.d_wout, rows * wstride * sizeof(float),
                            hipMemcpyDeviceToHost, down));
     if (want_iq) {
         for (size_t r = 0; r < rows; ++r) {
             if (!h->plan.cp[r % h->nch].has_iq_outputs)
                 continue;
-            HIP_TRY(hipMemcpyAsync(sl.h_out + o.iq + r * nsteps * 8, sl.d_iqout + r * nsteps, nsteps * sizeof(float2), hipMemcpyDeviceToHost, down));
+            HIP_TRY_F(hipMemcpyAsync(sl.h_out + o.iq + r * nsteps * 8, sl.d_iqout + r * nsteps, nsteps * sizeof(float2), hipMemcpyDeviceToHost, down));
         }
     }
-    HIP_TRY(hipMemcpyAsync(sl.h_out + o.axc, sl.d_axc, rows * static_cast<size_t>(nbatches), hipMemcpyDeviceToHost, down));
+    HIP_TRY_F(hipMemcpyAsync(sl.h_out + o.axc, sl.d_axc, rows * static_cast<size_t>(nbatches), hipMemcpyDeviceToHost, down));
     if (want_stats)
-        HIP_TRY(hipMemcpyAsync(sl.h_out + o.stats, sl.d_stats, rows * sizeof(mi_channel_stats), hipMemcpyDeviceToHost, down));
-    HIP_TRY(hipEventRecord(sl.done, down));
+        HIP_TRY_F(hipMemcpyAsync(sl.h_out + o.stats, sl.d_stats, rows * sizeof(mi_channel_stats), hipMemcpyDeviceToHost, down));
+    HIP_TRY_F(hipEventRecord(sl.done, down));
     return MI_OK;
 }
 
@@ -1321,6 +1339,8 @@ int slot_collect(mi_demod* h, int k) {
 int check_host_call(mi_demod* h, const uint8_t* const* iq, int nbatches, float* waveout, char* axc) {
     if (!h || !iq || !waveout || !axc)
         return fail(MI_ERR_INVALID, "NULL argument");
+    if (h->failed)
+        return fail(MI_ERR_HIP, kFailedMsg);
     if (nbatches < 1 || nbatches > h->max_batches)
         return fail(MI_ERR_INVALID, "nbatches out of range for this handle");
     return MI_OK;
@@ -1556,6 +1576,7 @@ int mi_demod_set_state(mi_demod* h, const void* buf, size_t len) {
     if (zrows)
         HIP_TRY(hipMemcpy2D(h->d_cplx, h->plane_stride * 8, o, mi::kAgcExtra * 8, mi::kAgcExtra * 8, zrows, hipMemcpyHostToDevice));
     h->first_call = hd.first_call != 0;
+    h->failed = false;
     return MI_OK;
 }
 
@@ -1575,6 +1596,15 @@ int mi_demod_last_path(mi_demod* h, int* time_parallel, int* unverified_rows) {
                 *unverified_rows += x.all_ok ? 0 : 1;
         }
     }
+    return MI_OK;
+}
+
+int mi_demod_pre_wave_timeouts(mi_demod* h, unsigned* count) {
+    if (!h || !count)
+        return fail(MI_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->gpu));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(count, h->d_pre_timeouts, sizeof(unsigned), hipMemcpyDeviceToHost));
     return MI_OK;
 }
 

@@ -187,6 +187,9 @@ int mi_demod_last_path(mi_demod* h, int* time_parallel, int* unverified_rows);
  * for this plan's own FFT nodes by hipRTC -- MI_OPT_LANE_FFT / MI_OPT_LANE_FFT_JIT). */
 enum { MI_STAGE1_EXCHANGE_FULL = 0, MI_STAGE1_EXCHANGE_PRUNED = 1, MI_STAGE1_LANE_FULL = 2, MI_STAGE1_LANE_PLAN = 3 };
 int mi_demod_last_stage1(mi_demod* h, int* kind);
+/* (diagnostic) how often, since the handle was created, a channel's wave of the serial kernel gave up waiting for the wave that walks
+ * its squelch pre-filter ahead (k_demod_pw; it then computes everything itself, same results): expected 0 */
+int mi_demod_pre_wave_timeouts(mi_demod* h, unsigned* count);
 
 /* TEST ENTRY -- stage 2 alone over caller-supplied planes: the per-channel loop of demodulate() (rtl_airband.cpp:517-669 with Squelch,
  * CTCSS, filters) run by the same kernels and along the same paths as mi_demod_process (serial / time-parallel by nbatches),

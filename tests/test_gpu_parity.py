@@ -838,6 +838,7 @@ def test_pre_filter_wave_same_bits_and_state(pkg, seed, per_call):
             pos = (call * per_call * WAVE_BATCH) * d.hop_bytes if call == 0 else (call * per_call * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
             wo, axc, iqo, _ = d.process([iq[pos:]], per_call, want_iq=True)
             outs.append((wo.copy(), axc.copy(), iqo.copy(), bytes(d.stats()), d.get_state().copy()))
+        assert d.pre_wave_timeouts() == 0, "a channel wave gave up waiting for its pre-filter wave"
         d.close()
         res[on] = outs
     for call, (a, b) in enumerate(zip(res[1], res[0])):
