@@ -42,6 +42,7 @@ struct input_t {
     int sample_rate;
     int centerfreq;
     pthread_mutex_t buffer_lock;
+    int buffer_pinned;  // (mirror only) the ring lives in page-locked memory (mi_host_alloc): the engine's copy engine reads it in place
 };
 
 // The wake-up the demod thread gives the output threads once per batch (reference: class Signal, boondock_airband.h:210-230).
@@ -90,7 +91,10 @@ struct device_t {
     channel_t* channels;
     int waveavail;
     size_t output_overrun_count;
-    mi_demod* engine;  // the MI355X engine bound to this device (init_demod)
+    mi_demod* engine;   // the MI355X engine bound to this device (init_demod); devices with equal plans share one
+    int engine_stream;  // ... as its stream number `engine_stream` of `engine_streams`
+    int engine_streams;
+    int engine_owner;   // this device destroys the engine
 };
 
 struct demod_params_t {
@@ -108,6 +112,8 @@ extern int fm_quadri_demod_selected;  // the -Q flag
 extern int devices_running;
 
 input_t* input_new_for_format(sample_format_t sfmt, int sample_rate, int centerfreq);  // ring sizing: config.cpp:799-805
+// the same ring in page-locked memory (mi_host_alloc): a batch that does not wrap is uploaded straight from the ring
+input_t* input_new_pinned_for_format(sample_format_t sfmt, int sample_rate, int centerfreq);
 void input_free(input_t* in);
 void circbuffer_append(input_t* const input, unsigned char* buf, size_t len);
 // Bytes between the read and the write position of the ring (taken under buffer_lock, rtl_airband.cpp:392-397).
@@ -124,8 +130,12 @@ device_t* device_new(input_t* in, const mi_channel_cfg* chans, int nch, int tau)
 std::vector<mi_channel_cfg> channel_cfgs_of(const device_t* dev);
 void device_free(device_t* dev);
 
-// init_demod() (rtl_airband.cpp:253-266): creates the engine of every device in [device_start, device_end).
+// init_demod() (rtl_airband.cpp:253-266): creates the engines of the devices in [device_start, device_end).  Devices whose plans are
+// equal -- same input format, rate, centre frequency, tau and channel list: the reference's "several dongles, one configuration" --
+// become the streams of ONE multi-stream engine, which demodulate() serves with one submit / wait pair per turn; a device with a
+// plan of its own gets an engine of its own (share_engines = 0: every device does).
 // Returns 0 or a negative mi_status (the caller maps it to error() like the VideoCore codes, rtl_airband.cpp:318-332).
+extern int share_engines;
 int init_demod(demod_params_t* params, Signal* signal, int device_start, int device_end, int gpu);
 void* demodulate(void* params);  // pthread entry, same signature as the reference
 

@@ -81,6 +81,47 @@ def test_replay_through_ring_equals_oracle(pkg, tmp_path, case):
             assert raw.size > 0
 
 
+@pytest.mark.gpu
+def test_four_devices_on_one_engine_equal_four_oracle_runs(pkg, tmp_path):
+    """The reference's one-thread-many-devices loop (rtl_airband.cpp:300-306, 381-422, 1044-1078): four devices with the same
+    configuration become the four streams of ONE engine, served by one submit / wait pair per turn from page-locked rings; a fifth
+    device with a configuration of its own gets its own engine.  Every device's audio and flags equal its own oracle run."""
+    _build()
+    centre = 120000000
+    _, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    other = [pkg.channel_cfg(centre + 250000, squelch_threshold_dbfs=-40), pkg.channel_cfg(centre + 500000, modulation=pkg.MOD_NFM)]
+    nbat = 6  # 3.8 MB of IQ per device: every ring wraps
+    caps, iqs, plans = [], [], []
+    for d in range(5):
+        ch = chans if d < 4 else other
+        iq, _ = gen_iq(pkg, dev, centre, ch, nbat, stream=d, gate_div=4 + d, **({} if d < 4 else {"active": lambda k: True}))
+        path = tmp_path / f"cap{d}.iq"
+        iq.tofile(path)
+        caps.append(str(path))
+        iqs.append(iq)
+        plans.append(ch)
+    cfg_a, cfg_b = tmp_path / "a.txt", tmp_path / "b.txt"
+    _write_cfg(cfg_a, dev, chans)
+    _write_cfg(cfg_b, dev, other)
+    cfgs = ",".join([str(cfg_a)] * 4 + [str(cfg_b)])
+    r = subprocess.run([TOOL, cfgs, ",".join(caps), str(tmp_path / "out")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert f"devices=5 engines=2 batches={','.join([str(nbat)] * 5)} overruns=0 overflows=0" in r.stdout, r.stdout
+    for d in range(5):
+        nb, owo, oaxc, _ = oracle_run(dev, plans[d], iqs[d], nbat)
+        assert nb == nbat
+        flags = open(tmp_path / f"out_d{d}_axc.txt").read().splitlines()
+        for c in range(len(plans[d])):
+            got = np.fromfile(tmp_path / f"out_d{d}_ch{c}.f32", dtype=np.float32)
+            assert_same(got, owo[c], f"device {d} ch{c} audio")
+            assert flags[c] == bytes(oaxc[c]).decode(), f"device {d} ch{c} axcindicate"
+    # the streams carry different signals: the devices really are different streams of the engine
+    a = np.fromfile(tmp_path / "out_d0_ch0.f32", dtype=np.float32)
+    b = np.fromfile(tmp_path / "out_d1_ch0.f32", dtype=np.float32)
+    assert not np.array_equal(a, b)
+
+
 # ---- the ring: input-helpers.cpp:37-63 is the spec ----
 
 class RingModel:
