@@ -106,7 +106,10 @@ def run_workload(pkg, args, workload, steps, warmup, gather_mode, rank, world, l
     nsteps = nbat * WAVE_BATCH
     hop = 2 * HOP
     nbytes = ((nsteps + AGC_EXTRA) * hop + 2 * (1 << fft_log) + 255) // 256 * 256
-    stream = torch.cuda.current_stream()
+    # the library's calls go to a stream of their own, not the NULL stream: its CU-restricted streams (MI_OPT_RESERVE_CUS) are blocking
+    # ones and would synchronise with the NULL stream
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
 
     # this rank's streams of the job (stream-major partition, the one the gloo test covers); their ids seed the generator
     lo, hi = shard.stream_range(rank, world, nstreams * world)

@@ -22,7 +22,7 @@ except ImportError:  # the C ABI itself has no torch dependency
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi_airband.so")
+LIB_PATH = os.environ.get("MI_AIRBAND_LIB") or os.path.join(_HERE, "libmi_airband.so")  # (the override: A/B of two builds, tools/ab_bench.sh)
 
 WAVE_RATE = 16000
 WAVE_BATCH = 2000
@@ -43,6 +43,7 @@ OPT_LANE_FFT = 10
 OPT_LANE_FFT_JIT = 11
 OPT_CORE_SPLIT = 12
 OPT_SPEC_HEAD = 13
+OPT_RESERVE_CUS = 15
 OPT_PRE_WAVE = 14
 SFMT_U8, SFMT_S8, SFMT_S16, SFMT_F32 = 1, 2, 3, 4
 

@@ -184,12 +184,16 @@ struct TpArgs {
     size_t rec_stride;
     int* tstart;                               // [nrows*nseg][8]
     int* need;                                 // [nrows*nseg]
+    int redo_listed;                           // k_tp_fix appends to `redo` (the first round; k_tp_settle's rounds do not)
+    int* redo;                                 // [1 + nrows*nseg] work list of k_tp_redo: the count, then r * nseg + k of every segment to re-run
     TpFinal* fin;                              // [nrows]
     int* diag;                                 // [nrows][4] segments not accepted in scan 0..3, then [nrows][4] core-chain block counts
     int seg_lpw;                               // lanes per wave of k_tp_seg, 0 = auto (MI_OPT_TP_SEG_LANES)
     int eager_samples;                         // (diagnostic, MI_AIRBAND_TP_EAGER=1) segment lanes request every block's samples a block ahead
     int core_lead;                             // ... how many blocks its noise-floor wave may run ahead (0 = default)
     int core_split;                            // the noise-floor passes of the core chain on a wave of their own (k_tp_core2)
+    int agc_hint;                              // segment lanes guess agcavgfast as the channel's last committed value (else 0.5)
+    int core_decay;                            // ... the decays after bursts walked ahead by two more waves (decay_wave)
     int core_guess;                            // ... taken by guess-and-verify rounds instead of systolic passes (nf_chain_guess64)
 };
 inline uint32_t tp_chunk_unit(uint32_t L) {  // lcm(L, WAVE_BATCH = 2000) for L = 2^k >= 16: 2000 = 16 * 125

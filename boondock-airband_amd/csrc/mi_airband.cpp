@@ -116,6 +116,8 @@ struct mi_demod {
     bool opt_spec_head = true;   // MI_OPT_SPEC_HEAD: overlapped calls start their first segments from a guessed state (see TpArgs)
     int opt_tp_eager = 0;        // (diagnostic, MI_AIRBAND_TP_EAGER)
     int opt_core_lead = 0;       // (diagnostic, MI_AIRBAND_CORE_LEAD) blocks the noise-floor wave may run ahead, 0 = default
+    int opt_agc_hint = 1;        // (diagnostic, MI_AIRBAND_AGC_HINT=0) segment lanes start from agcavgfast = 0.5 instead of the channel's last value
+    int opt_core_decay = 1;      // (diagnostic, MI_AIRBAND_CORE_DECAY=0) no decay waves: the walking wave steps every decay itself
     int opt_core_guess = 1;      // (diagnostic, MI_AIRBAND_CORE_GUESS=0) the noise-floor wave walks systolic passes only, no guess-and-verify rounds
     bool opt_core_split = true;  // MI_OPT_CORE_SPLIT: noise-floor passes of the core chain on their own wave (k_tp_core2)
     bool core_split_ok = false;  // ... the plan allows it: automatic squelch levels with a cap factor >= 1 on every channel
@@ -125,6 +127,12 @@ struct mi_demod {
     bool early_input = false;  // MI_OPT_EARLY_INPUT: the IQ of a call is valid when the call is made
     bool chain_live = false;   // d_core_carry holds the chain state at the end of the previous call (it was time-parallel)
     hipStream_t seg_stream[kSegStreams] = {nullptr};  // the speculative segment passes (need core(i) only)
+    // MI_OPT_RESERVE_CUS: twins of the front and segment streams whose kernels keep off the last `reserve_cus` CUs (see enqueue)
+    hipStream_t front_stream_m = nullptr;
+    hipStream_t seg_stream_m[kSegStreams] = {nullptr};
+    int opt_reserve_cus = -1;  // -1 auto: 32 for handles of up to 64 rows, none beyond; 0 none
+    int last_masked = -1;      // which side the previous time-parallel call used
+    int masked_state = 0;      // 0 undecided, 1 the masked twins carry the time-parallel passes of this handle, 2 the plain streams do
     int tp_chunks[kSets] = {};
     mi::TpCore* d_core_carry = nullptr;
     float* d_full0 = nullptr;
@@ -208,6 +216,7 @@ struct mi_demod {
     const float* set_out_hi[kSets] = {};
     int* d_tstart = nullptr;
     int* d_need = nullptr;
+    int* d_redo = nullptr;  // [1 + rows*max_seg]: count, then the (row, segment) indices k_tp_fix leaves for k_tp_redo
     mi::TpFinal* d_fin = nullptr;
     int* d_diag = nullptr;
     uint32_t last_nseg[kSets] = {};
@@ -262,6 +271,12 @@ void tuning_from_env(mi_demod* h) {
         h->opt_tp_eager = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_CORE_LEAD"))
         h->opt_core_lead = std::max(0, std::atoi(e));
+    if (const char* e = get("MI_AIRBAND_RESERVE_CUS"))
+        h->opt_reserve_cus = std::max(-1, std::atoi(e));
+    if (const char* e = get("MI_AIRBAND_AGC_HINT"))
+        h->opt_agc_hint = std::atoi(e) != 0;
+    if (const char* e = get("MI_AIRBAND_CORE_DECAY"))
+        h->opt_core_decay = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_CORE_GUESS"))
         h->opt_core_guess = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_PRE_WAVE"))
@@ -544,12 +559,15 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         ta.rec_stride = static_cast<size_t>(h->rows) * h->tp_max_seg;
         ta.tstart = h->d_tstart;
         ta.need = h->d_need;
+        ta.redo = h->d_redo;
         ta.fin = h->d_fin;
         ta.diag = h->d_diag;
         ta.seg_lpw = h->opt_tp_lpw;
         ta.core_split = (h->opt_core_split && h->core_split_ok) ? 1 : 0;
         ta.core_lead = h->opt_core_lead;
         ta.core_guess = h->opt_core_guess;
+        ta.core_decay = h->opt_core_decay;
+        ta.agc_hint = h->opt_agc_hint;
         ta.eager_samples = h->opt_tp_eager;
         // Speculative head: when this call's segment pass may run under the previous call's tail at all (seg_early) and that call
         // left what the warm-up needs (aggregates, core states at boundaries of the same segment length, TP_W steps of them),
@@ -578,7 +596,42 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             return c;
         };
         const bool first_call = h->first_call;
-        hipStream_t fs = h->front_stream;
+        // The wide passes of a call (stage 1, aggregates, segment pass: thousands of waves that hold most of a SIMD's registers for a
+        // millisecond) run beside the latency-bound kernels of its neighbours: the core chains, and the tail (scan / fix / redo /
+        // settle / finish: a handful of lanes, 280-430 VGPRs a wave), which then wait for a wide wave to retire before they can
+        // start at all -- 1.5 ms per call for 0.65 ms of work.  So on plans of few rows the wide passes keep off a few CUs
+        // (hipExtStreamCreateWithCUMask), where the others always find room.  Such a stream is a blocking one (it synchronises
+        // with the NULL stream): the twins are created at the handle's first time-parallel call and used by every call whose stream
+        // is not the NULL stream.
+        if (h->masked_state == 0) {
+            const int want = h->opt_reserve_cus >= 0 ? h->opt_reserve_cus : (h->rows <= 64 ? 32 : 0);
+            h->masked_state = 2;
+            hipDeviceProp_t prop{};
+            if (want > 0 && hipGetDeviceProperties(&prop, h->gpu) == hipSuccess && prop.multiProcessorCount >= want + 32) {
+                const int ncu = prop.multiProcessorCount, keep = ncu - want;
+                std::vector<uint32_t> mask(static_cast<size_t>((ncu + 31) / 32), 0u);
+                for (int i = 0; i < keep; ++i)
+                    mask[static_cast<size_t>(i) / 32] |= 1u << (i % 32);
+                hipError_t me = hipExtStreamCreateWithCUMask(&h->front_stream_m, static_cast<uint32_t>(mask.size()), mask.data());
+                for (hipStream_t& ssm : h->seg_stream_m)
+                    if (me == hipSuccess)
+                        me = hipExtStreamCreateWithCUMask(&ssm, static_cast<uint32_t>(mask.size()), mask.data());
+                if (me == hipSuccess)
+                    h->masked_state = 1;
+                else
+                    (void)hipGetLastError();  // (no such streams here: the plain ones serve)
+            }
+        }
+        // (a call on the NULL stream takes the plain streams whatever the handle decided; changing sides between calls is rare and
+        //  costs a host wait: the passes of consecutive calls are ordered by their stream, not by events)
+        const bool masked = h->masked_state == 1 && s != nullptr;
+        if (h->last_masked >= 0 && h->last_masked != (masked ? 1 : 0)) {
+            HIP_TRY(hipStreamSynchronize(h->last_masked ? h->front_stream_m : h->front_stream));
+            for (int i = 0; i < mi_demod::kSegStreams; ++i)
+                HIP_TRY(hipStreamSynchronize(h->last_masked ? h->seg_stream_m[i] : h->seg_stream[i]));
+        }
+        h->last_masked = masked ? 1 : 0;
+        hipStream_t fs = masked ? h->front_stream_m : h->front_stream;
         auto stage1 = [&](const mi::TpArgs& c) -> hipError_t {  // the windows whose magnitudes are the chunk's squelch samples
             mi::ChannelizeArgs cc = ca;
             const uint32_t f0 = first_call ? (c.first_chunk ? 0u : c.step0 + mi::kAgcExtra) : c.step0;
@@ -630,7 +683,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             HIP_TRY(hipEventRecord(ev(i, 3), h->aux_stream));
             HIP_TRY(mi::launch_tp_core(c, h->aux_stream));
             HIP_TRY(hipEventRecord(ev(i, 4), h->aux_stream));
-            hipStream_t ss = h->seg_stream[i % mi_demod::kSegStreams];
+            hipStream_t ss = masked ? h->seg_stream_m[i % mi_demod::kSegStreams] : h->seg_stream[i % mi_demod::kSegStreams];
             // A segment pass needs core(i).  It also has to wait for the previous call (ev_head) where it touches what
             // that call's tail still owns: the carried ChanState (the lanes of the first TP_W / L + 1 segments start
             // from it), the audio lookahead (written by the last segments) and the caller's audio buffer if it is the
@@ -814,7 +867,7 @@ void mi_demod_destroy(mi_demod* h) {
     (void)hipDeviceSynchronize();  // calls may still be in flight on the handle's own streams
     void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_t1, h->d_prune_t2, h->d_prune_rank, h->d_l64_chan, h->d_l64_chan_full, h->d_l64_tickets, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx_set[0], h->d_cplx_set[1], h->d_carry_set[0], h->d_carry_set[1], h->d_carry_set[2], h->d_carry_set[3],
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_pre_timeouts,
-                    h->d_rows,   h->d_tstart, h->d_need, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_fullbound, h->d_afc_spec};
+                    h->d_rows,   h->d_tstart, h->d_need, h->d_redo, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_fullbound, h->d_afc_spec};
     for (void* p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -856,6 +909,11 @@ void mi_demod_destroy(mi_demod* h) {
         (void)hipEventDestroy(h->ev_head);
     if (h->aux_stream)
         (void)hipStreamDestroy(h->aux_stream);
+    if (h->front_stream_m)
+        (void)hipStreamDestroy(h->front_stream_m);
+    for (hipStream_t ss : h->seg_stream_m)
+        if (ss)
+            (void)hipStreamDestroy(ss);
     if (h->front_stream)
         (void)hipStreamDestroy(h->front_stream);
     for (hipStream_t ss : h->seg_stream)
@@ -1023,6 +1081,7 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
             TRY_OR_BAIL(dalloc(&h->d_rec[q], static_cast<size_t>(mi::TP_NREC) * rows * h->tp_max_seg));
         TRY_OR_BAIL(dalloc(&h->d_tstart, rows * h->tp_max_seg * 8));
         TRY_OR_BAIL(dalloc(&h->d_need, rows * h->tp_max_seg));
+        TRY_OR_BAIL(dalloc(&h->d_redo, rows * h->tp_max_seg + 1));
         TRY_OR_BAIL(dalloc(&h->d_fin, rows));
         TRY_OR_BAIL(hipMemset(h->d_fin, 0, rows * sizeof(mi::TpFinal)));
         TRY_OR_BAIL(dalloc(&h->d_core_carry, rows));
@@ -1788,6 +1847,11 @@ int mi_demod_set_option(mi_demod* h, int option, int value) {
             return MI_OK;
         case MI_OPT_SPEC_HEAD:
             h->opt_spec_head = value != 0;
+            return MI_OK;
+        case MI_OPT_RESERVE_CUS:
+            if (h->masked_state != 0)
+                return fail(MI_ERR_INVALID, "MI_OPT_RESERVE_CUS is decided at the handle's first time-parallel call: set it before");
+            h->opt_reserve_cus = value < 0 ? -1 : value;
             return MI_OK;
         case MI_OPT_PRE_WAVE:
             h->opt_pre_wave = value < 0 ? -1 : (value != 0 ? 1 : 0);

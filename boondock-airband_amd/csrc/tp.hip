@@ -316,41 +316,57 @@ __device__ __forceinline__ float nf_chain_guess64(float& nf, const float op, NfG
     // the predictions of the first round: the increments of the previous group's last three blocks (lanes 60 .. 62 after the shift
     // at its end)
     uint32_t h0 = __builtin_amdgcn_readlane(dh, 60), h1 = __builtin_amdgcn_readlane(dh, 61), h2 = __builtin_amdgcn_readlane(dh, 62);
-    int kk = 0, rounds = 0;
+    uint32_t kk = 0;
+    int rounds = 0;
     for (;;) {
         // lane kk + n: the sum of the n predicted increments h0, h1, h2, h0, ...
-        const uint32_t n = static_cast<uint32_t>(lane - kk);
+        const uint32_t n = static_cast<uint32_t>(lane) - kk;
         const uint32_t q = mul24(n, 43u) >> 7;  // n / 3 for n < 128 (lanes below kk: anything)
         const uint32_t r = n - mul24(q, 3u);
-        const uint32_t part = (r == 0u) ? 0u : ((r == 1u) ? h0 : h0 + h1);
+        const uint32_t part = mul24(min(r, 1u), h0) + mul24(r >> 1, h1);  // r == 0: 0, r == 1: h0, r == 2: h0 + h1
         const uint32_t g = nfb + mul24(q, h0 + h1 + h2) + part;
         const float o = noise_floor_step(__uint_as_float(g), op);
         const uint32_t ob = __float_as_uint(o);
         const uint32_t oprev = wave_shr1_u32(ob, 0u);
         // bit i: lane i + 1 exists, lies behind kk and its guess is not the true result of the lane before
         const unsigned long long bad = ((__ballot(oprev != g) >> 1) | (1ull << 63)) & (~0ull << kk);
-        // lanes kk .. (first bad bit) had a proven input: no bad bit below the lane (mbcnt: set bits of the mask below the lane)
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(bad >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bad), 0u));
-        const bool settled = below == 0u && lane >= kk;
-        const int last = __ffsll(static_cast<long long>(bad)) - 1;
+        const uint32_t last = static_cast<uint32_t>(__ffsll(static_cast<long long>(bad)) - 1);  // lanes kk .. last had a proven input
+        const bool settled = n <= last - kk;  // (unsigned: lanes below kk are far above)
+        // lanes whose step is (by their guess) one below the floor: a run of them behind `last` is walked by systolic passes below
+        const unsigned long long dips = __ballot(op < __uint_as_float(g));
         if (settled)
             vnf = o;
         const uint32_t d = ob - g;
         if (settled && d + 1u - inc <= 2u)
             dh = d;
         nfb = __builtin_amdgcn_readlane(ob, last);
-        kk = last + 1;
+        kk = last + 1u;
         ++rounds;
-        if (kk >= 64)
+        if (kk >= 64u)
             break;
-        if (__builtin_expect(rounds >= 8, 0)) {  // the history does not predict this stretch: systolic passes for the rest of the group
-            if (lane >= kk)
-                vnf = nf_chain_min(__uint_as_float(nfb), op, 64 - kk);
-            nfb = __builtin_amdgcn_readlane(__float_as_uint(vnf), 63);
-            break;
+        // Steps below the floor come in runs (full_ stays under the floor for a few blocks) and each one is a misprediction of its
+        // own: L of them cost L rounds, or L passes of 6 instructions.  (The guesses judge them from above -- a lane that is not
+        // below the floor after all is walked correctly just the same.)  After eight rounds the rest of the group goes this way.
+        const unsigned long long behind = ~(dips >> kk);
+        uint32_t run = (behind == 0ull) ? 64u - kk : static_cast<uint32_t>(__ffsll(static_cast<long long>(behind)) - 1);
+        if (__builtin_expect(rounds >= 8, 0))
+            run = 64u - kk;
+        if (run != 0u) {
+            run = min(run, 64u - kk);
+            float w = vnf;
+            if (static_cast<uint32_t>(lane) >= kk)
+                w = nf_chain_min(__uint_as_float(nfb), op, static_cast<int>(run));
+            if (static_cast<uint32_t>(lane) - kk < run)  // lanes kk .. kk + run - 1
+                vnf = w;
+            kk += run;
+            nfb = __builtin_amdgcn_readlane(__float_as_uint(vnf), kk - 1u);
+            if (kk >= 64u)
+                break;
+            h0 = h1 = h2 = inc;  // (behind a dip the pattern starts afresh)
+            continue;
         }
         // the increments of the last three settled blocks (a lane that took a step below the floor keeps what it had before)
-        h0 = __builtin_amdgcn_readlane(dh, (last + 62) & 63), h1 = __builtin_amdgcn_readlane(dh, (last + 63) & 63), h2 = __builtin_amdgcn_readlane(dh, last);
+        h0 = __builtin_amdgcn_readlane(dh, last + 62u), h1 = __builtin_amdgcn_readlane(dh, last + 63u), h2 = __builtin_amdgcn_readlane(dh, last);
     }
     n_rounds += rounds;
     // the next group's lane j is block 64 + j; 63 is a multiple of three, so lane j + 1 of this group is the same class
@@ -417,6 +433,7 @@ __device__ __forceinline__ void ema_trial(const float (&ys)[16], const float c, 
 // (14-16 times per channel-minute of the gated test signal).  Every wait is bounded; if one runs out wave 1 walks the chain itself from there (`solo`).
 #ifdef MI_CORE_PROF
 #define CORE_PROF(...) __VA_ARGS__
+static __device__ int g_prof_unsettled;  // (diagnostic build: blocks a lone fix lane took through the sample path; one lane at a time looks at it)
 __device__ __forceinline__ unsigned long long prof_now() {
     return wall_clock64();  // 100 MHz
 }
@@ -425,7 +442,9 @@ __device__ __forceinline__ unsigned long long prof_now() {
 #endif
 constexpr unsigned kNfRing = 2048;
 constexpr unsigned kOpRing = 2048;
-constexpr unsigned kFetchTrip = 512;  // blocks a fetch wave requests at a time (32 loads per lane in flight)
+constexpr unsigned kFetchTrip = 512;
+constexpr unsigned kDecRing = 256;  // entries of a decay record (a power of two)
+constexpr unsigned kDecMax = 192;   // blocks a decay wave follows one decay  // blocks a fetch wave requests at a time (32 loads per lane in flight)
 constexpr unsigned kShareSpin = 2u * 1000u * 1000u;
 struct CoreShare {
     float nfring[kNfRing];  // noise floor after block b, at b % kNfRing
@@ -436,6 +455,16 @@ struct CoreShare {
     float x0ring[kOpRing];  // blk_x0
     float xmring[kOpRing];  // blk_xm
     unsigned fetch_next[2];  // per fetch wave: first block of the trip it has not delivered yet (everything below both is there)
+    // The decays after a burst (capped_ falling from the cap until it meets full_ again, ~110 blocks of 32 dependent operations), walked
+    // ahead of wave 1 by the two decay waves (waves 4 and 5): per block the value entering it, the bare moving average after its 16
+    // samples and the largest value on the way -- a function of the entering value and the samples alone.  Wave 1 takes an entry only
+    // if its own capped_ IS the entering value, bit for bit, and judges with its own cap whether the cap binds.
+    struct DecayRec {
+        float cin[kDecRing], cout[kDecRing], emax[kDecRing];
+        unsigned start;   // block of entry 0
+        unsigned done;    // entries delivered
+        unsigned active;  // the decay wave is still extending it
+    } dec[2];
     unsigned w0_done;       // wave 0 has delivered every block below this one (since its last restart)
     unsigned w1_pos;        // block wave 1 is at: wave 0 stays within the ring's reach of it
     unsigned rb_seq, rb_ack, rb_blk;  // restart request of wave 1 / its acknowledgement
@@ -508,7 +537,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
     const uint32_t bps_log = 31u - static_cast<uint32_t>(__builtin_clz(bps));
 
     int n_run = 0, n_single = 0, n_step = 0, n_fail = 0;  // diagnostics: blocks per path, failed hypotheses
-    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_wait = 0, t_stepping = 0, t_mark = 0; int n_waits = 0;)
+    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_wait = 0, t_stepping = 0, t_mark = 0; int n_waits = 0, n_from_rec = 0, n_reclook = 0; unsigned long long t_recwait = 0;)
     // kSplit: the noise-floor passes come from the chain wave (CoreShare).  `own`: this wave advanced the noise floor itself since it
     // last took a value from there (single blocks, decays): the next value taken is only good if the chain wave agrees on the one
     // before it.  `solo`: the chain wave was given up on (a wait ran out): from then on this wave walks the chain itself.
@@ -767,6 +796,62 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                             bool ok = false;
                             float nf_in = nf, cap_in = cap, c_in = c;
                             if (kSplit && ring_ok) {
+                                // ---- has a decay wave walked these blocks from exactly this capped_? ----
+                                const uint32_t b1 = g0 + static_cast<uint32_t>(kk) + 1u;
+                                int hit = -1;
+                                uint32_t rstart = 0, rdone = 0;
+                                CORE_PROF(const unsigned long long t_rw = prof_now();)
+                                for (unsigned spin = 0;; ++spin) {
+                                    bool coming = false;
+#pragma unroll
+                                    for (int d = 0; d < 2; ++d) {
+                                        const uint32_t st = share_peek(&sh->dec[d].start), dn = share_peek(&sh->dec[d].done), ac = share_peek(&sh->dec[d].active);
+                                        if (b1 - st < dn)
+                                            hit = d, rstart = st, rdone = dn;
+                                        else if (ac && b1 - st < kDecMax)
+                                            coming = true;  // it is on its way here: cheaper to wait than to walk the same chain
+                                    }
+                                    if (hit >= 0 || !coming || spin > 20000u)
+                                        break;
+                                    __builtin_amdgcn_s_sleep(2);
+                                }
+                                CORE_PROF(t_recwait += prof_now() - t_rw; ++n_reclook;)
+                                if (hit >= 0) {
+                                    share_order();
+                                    const uint32_t idx = g0 + static_cast<uint32_t>(lane) - rstart;
+                                    const bool have = lane > kk && idx < rdone;
+                                    const uint32_t slot = idx & (kDecRing - 1u);
+                                    const float r_in = *(lds_vf32*)&sh->dec[hit].cin[slot], r_out = *(lds_vf32*)&sh->dec[hit].cout[slot],
+                                                r_max = *(lds_vf32*)&sh->dec[hit].emax[slot];
+                                    // the record is one chain; its link to this wave's state is the value entering block kk + 1
+                                    // (the shift outside any lane-dependent choice: a lane switched off for it reads as `c` to its neighbour)
+                                    const float r_out_below = wave_shr1(r_out, c);
+                                    const float want_in = (lane == kk + 1) ? c : r_out_below;
+                                    nf_in = wave_shr1(ringv, nf);
+                                    cap_in = cap_of(p, nf_in);
+                                    nfL = ringv, capL = cap_of(p, ringv);
+                                    const bool okr = have && __float_as_uint(r_in) == __float_as_uint(want_in) && cur.fm >= 0.0f && r_max < capL && r_in != fe_prev &&
+                                                     __builtin_fminf(r_in, nf_in) == __builtin_fminf(fe_prev, nf_in);
+                                    const int nrec = min(trailing_ones_from(__ballot(okr), kk + 1), nb - 1 - kk);
+                                    if (nrec > 0) {
+                                        if (boundary && lane > kk && lane <= kk + nrec) {
+                                            TpCore t;  // the state at the start of the lane's block
+                                            t.nf = nf_in, t.cap = cap_in, t.c = r_in, t.full = fe_prev;
+                                            core[(g0 + lane) >> bps_log] = t;
+                                        }
+                                        kk += nrec;
+                                        nf = rl(nfL, kk);
+                                        cap = rl(capL, kk);
+                                        c = rl(r_out, kk);
+                                        cL = r_out;
+                                        fe_k = rl(cur.fe, kk);
+                                        n_step += nrec;
+                                        CORE_PROF(n_from_rec += nrec;)
+                                        continue;
+                                    }
+                                }
+                            }
+                            if (kSplit && ring_ok) {
                                 float em1 = 0.0f;
                                 if (lane > kk) {
 #pragma unroll 1
@@ -844,8 +929,8 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
         }
         fe_group = rl(cur.fe, 63);
     }
-    CORE_PROF(if (lane == 0 && r < 8) printf("core w1 row %d: total %llu us  wait-w0 %llu us (%d waits)  stepping %llu us  run %d accepted-runs %d step %d fail %d rollback %d solo %d\n", r,
-                                           (prof_now() - t_begin) / 100, t_wait / 100, n_waits, t_stepping / 100, n_run, n_single, n_step, n_fail, n_rollback, (int)solo);)
+    CORE_PROF(if (lane == 0 && r < 8) printf("core w1 row %d: total %llu us  wait-w0 %llu us (%d waits)  stepping %llu us (record waits %llu us, %d looks)  run %d accepted-runs %d step %d (from records %d) fail %d rollback %d solo %d\n", r,
+                                           (prof_now() - t_begin) / 100, t_wait / 100, n_waits, t_stepping / 100, t_recwait / 100, n_reclook, n_run, n_single, n_step, n_from_rec, n_fail, n_rollback, (int)solo);)
     if (kSplit && lane == 0)
         share_post(&sh->quit, 1u);
     if (lane == 0) {
@@ -867,14 +952,198 @@ __global__ __launch_bounds__(64) void k_tp_core(const TpArgs a) {
     core_walk<false>(a, nullptr, threadIdx.x);
 }
 
-__global__ __launch_bounds__(256) void k_tp_core2(const TpArgs a) {
+// ---- waves 4 and 5 of k_tp_core2: the decays, ahead of wave 1 ----
+// A decay starts where the saturated regime ends: the first block whose SATURATED test fails behind one that passed, with
+// capped_ == the cap entering it.  The decay waves find those blocks in what wave 0 has delivered (the same test as wave 1's, on
+// the same rings), take turns, and follow each decay for up to kDecMax blocks with wave 1's own lane-systolic rounds, leaving
+// (value in, value out, largest value) per block in their record.  Nothing here is trusted: see CoreShare::DecayRec.
+__device__ __forceinline__ void decay_wave(const TpArgs& a, LdsShare* sh, const unsigned w, const int lane) {
+    const int r = blockIdx.x;
+    const int row = a.rows[r];
+    const ChanParams p = a.cp[row % a.nch];
+    const float* __restrict__ x = a.mag + static_cast<size_t>(row) * a.plane_stride + kAgcExtra;
+    const uint32_t nblk = a.blk1;
+    const float nf_carry = a.core_carry[r].nf;
+    const float nfac = static_cast<float>(1.0 - static_cast<double>(0.99f));
+    uint32_t sb = a.blk0;   // the group being scanned
+    bool prev_sat = false;  // the block before it passed the SATURATED test
+    unsigned edges_seen = 0, rb_seen = 0, idle = 0;
+    uint32_t rec_end = 0;   // wave 1 has to be past this block before the record is overwritten
+    CORE_PROF(unsigned long long t_dec = 0, t_hold = 0, t_m = 0; int n_dec = 0, n_blk = 0, n_met = 0;)
+    for (;;) {
+        const unsigned quit = share_peek(&sh->quit), w0_done = share_peek(&sh->w0_done), rs = share_peek(&sh->rb_seq), ack = share_peek(&sh->rb_ack),
+                       w1_pos = share_peek(&sh->w1_pos);
+        if (quit || sb >= nblk)
+            break;
+        if (rs != rb_seen) {  // wave 0 was sent back: what was scanned behind that block was scanned with another floor
+            if (ack != rs) {
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            rb_seen = rs;
+            const uint32_t rb = share_peek(&sh->rb_blk);
+            if (rb < sb) {
+                sb = a.blk0 + ((rb - a.blk0) & ~63u);
+                prev_sat = false;
+            }
+            continue;
+        }
+        if (w1_pos >= sb + 64u) {  // wave 1 is past this group (it walks the decays it finds no record for itself)
+            sb = a.blk0 + ((w1_pos - a.blk0) & ~63u);
+            prev_sat = false;
+            continue;
+        }
+        const uint32_t n = min(64u, nblk - sb);
+        if (w0_done < sb + n) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++idle > 8u * kShareSpin)
+                break;
+            continue;
+        }
+        idle = 0;
+        share_order();
+        const uint32_t b = sb + static_cast<uint32_t>(lane), slot = b & (kOpRing - 1u);
+        const float vnf = *(lds_vf32*)&sh->nfring[b & (kNfRing - 1u)];
+        const float nf_first = (sb > a.blk0) ? *(lds_vf32*)&sh->nfring[(sb - 1u) & (kNfRing - 1u)] : nf_carry;
+        const float nf_prev = wave_shr1(vnf, nf_first);
+        const float cap_prev = cap_of(p, nf_prev), capj = cap_of(p, vnf);
+        const float x0 = *(lds_vf32*)&sh->x0ring[slot], xm = *(lds_vf32*)&sh->xmring[slot], fm = *(lds_vf32*)&sh->fmring[slot], fe_prev = *(lds_vf32*)&sh->opring[slot];
+        const bool sat = static_cast<uint32_t>(lane) < n && fm >= 0.0f && capped_step(cap_prev, x0, capj) == capj && xm >= capj &&
+                         __builtin_fminf(cap_prev, nf_prev) == __builtin_fminf(fe_prev, nf_prev);
+        const unsigned long long m = __ballot(sat);
+        unsigned long long edges = ~m & ((m << 1) | (prev_sat ? 1ull : 0ull)) & (n == 64u ? ~0ull : ((1ull << n) - 1ull));
+        prev_sat = (m >> 63) != 0ull;
+        while (edges) {
+            const int e = __ffsll(static_cast<long long>(edges)) - 1;
+            edges &= edges - 1ull;
+            if ((edges_seen++ & 1u) != w)
+                continue;
+            // ---- follow the decay that starts at block sb + e from capped_ == the cap entering it ----
+            __attribute__((address_space(3))) CoreShare::DecayRec* rec = &sh->dec[w];
+            CORE_PROF(t_m = prof_now();)
+            for (unsigned spin = 0; share_peek(&sh->w1_pos) < rec_end && !share_peek(&sh->quit) && spin < 8u * kShareSpin; ++spin)
+                __builtin_amdgcn_s_sleep(2);  // wave 1 may still be reading the previous record
+            CORE_PROF(t_hold += prof_now() - t_m; t_m = prof_now(); ++n_dec;)
+            const uint32_t e0 = sb + static_cast<uint32_t>(e);
+            if (lane == 0) {
+                share_post(&rec->done, 0u);
+                share_post(&rec->active, 1u);
+            }
+            share_order();
+            if (lane == 0)
+                share_post(&rec->start, e0);
+            float c = rl(cap_prev, e);
+            uint32_t count = 0;
+            bool stop = false;
+            for (uint32_t base_blk = e0; !stop && count < kDecMax && base_blk < nblk; base_blk += 64u) {
+                const uint32_t nbk = min(min(64u, nblk - base_blk), kDecMax - count);
+                const uint32_t at = min(base_blk + static_cast<uint32_t>(lane), nblk - 1u);
+                const float4* __restrict__ sp = reinterpret_cast<const float4*>(x + static_cast<size_t>(at) * 16);
+                const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+                const float yv[16] = {s0.x * nfac, s0.y * nfac, s0.z * nfac, s0.w * nfac, s1.x * nfac, s1.y * nfac, s1.z * nfac, s1.w * nfac,
+                                      s2.x * nfac, s2.y * nfac, s2.z * nfac, s2.w * nfac, s3.x * nfac, s3.y * nfac, s3.z * nfac, s3.w * nfac};
+                // full_ after the lane's block, if the fetch waves have it yet (merged again: the decay is over)
+                const uint32_t fetched = min(share_peek(&sh->fetch_next[0]), share_peek(&sh->fetch_next[1]));
+                const float fe_blk = *(lds_vf32*)&sh->opring[(base_blk + static_cast<uint32_t>(lane) + 1u) & (kOpRing - 1u)];
+                const bool fe_known = base_blk + static_cast<uint32_t>(lane) + 1u < fetched;
+                float cL = c;
+                uint32_t base = 0;
+                // The first blocks of a decay, one at a time while the cap still binds (capped_ starts AT the cap): the trial, and where
+                // it fails the capped recurrence with the cap of the floor wave 0 has for the block -- what wave 1 does with them.
+                // Their entries say "not a bare average" (largest value = +inf): wave 1 steps those blocks itself and finds the
+                // chain again behind them.
+                while (base_blk == e0 && base < nbk && base < 8u) {
+                    const uint32_t blk = base_blk + base;
+                    for (unsigned spin = 0; share_peek(&sh->w0_done) <= blk && spin < kShareSpin; ++spin)
+                        __builtin_amdgcn_s_sleep(1);
+                    const float capb = cap_of(p, uni(*(lds_vf32*)&sh->nfring[blk & (kNfRing - 1u)]));
+                    float cs_l, em_l;
+                    ema_trial(yv, c, cs_l, em_l);
+                    const float cs = rl(cs_l, static_cast<int>(base)), em = rl(em_l, static_cast<int>(base));
+                    if (em < capb)
+                        break;  // the cap no longer binds: the rounds below take over from this block
+                    const int l = static_cast<int>(base);
+                    const float xs[16] = {rl(s0.x, l), rl(s0.y, l), rl(s0.z, l), rl(s0.w, l), rl(s1.x, l), rl(s1.y, l), rl(s1.z, l), rl(s1.w, l),
+                                          rl(s2.x, l), rl(s2.y, l), rl(s2.z, l), rl(s2.w, l), rl(s3.x, l), rl(s3.y, l), rl(s3.z, l), rl(s3.w, l)};
+                    float cc = c;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const float t = (xs[j] >= capb) ? capb : __int_as_float(0x7f800000);
+                        const float ev = cc * 0.99f + rl(yv[j], l);
+                        const float mv = (ev < capb) ? ev : capb;
+                        cc = (cc >= t) ? capb : mv;
+                    }
+                    if (lane == 0) {
+                        const uint32_t idx = (blk - e0) & (kDecRing - 1u);
+                        *(lds_vf32*)&rec->cin[idx] = c, *(lds_vf32*)&rec->cout[idx] = cc, *(lds_vf32*)&rec->emax[idx] = __int_as_float(0x7f800000);
+                    }
+                    (void)cs;
+                    c = cc;
+                    cL = c;
+                    ++base;
+                    share_order();
+                    if (lane == 0)
+                        share_post(&rec->done, blk - e0 + 1u);
+                }
+                for (; base < nbk && !stop; base += 16u) {
+                    float c_in = c, em1 = 0.0f;
+                    if (static_cast<uint32_t>(lane) >= base) {
+#pragma unroll 1
+                        for (int t = 0; t < 16; ++t) {
+                            c_in = wave_shr1(cL, c);
+                            float cs1;
+                            ema_trial(yv, c_in, cs1, em1);
+                            cL = cs1;
+                        }
+                    }
+                    const uint32_t top = min(base + 16u, nbk);
+                    const bool mine = static_cast<uint32_t>(lane) >= base && static_cast<uint32_t>(lane) < top;
+                    if (mine) {
+                        const uint32_t idx = (base_blk - e0 + static_cast<uint32_t>(lane)) & (kDecRing - 1u);
+                        *(lds_vf32*)&rec->cin[idx] = c_in, *(lds_vf32*)&rec->cout[idx] = cL, *(lds_vf32*)&rec->emax[idx] = em1;
+                    }
+                    share_order();
+                    if (lane == 0)
+                        share_post(&rec->done, base_blk - e0 + top);
+                    c = rl(cL, static_cast<int>(top) - 1);
+                    // over when capped_ has met full_ again, or climbed back to (about) where it started: the next burst
+                    const unsigned long long met = __ballot(mine && fe_known && cL == fe_blk);
+                    stop = met != 0ull || share_peek(&sh->quit) != 0u || share_peek(&sh->rb_seq) != rb_seen;
+                }
+                count += nbk;
+            }
+            rec_end = e0 + count;
+            CORE_PROF(t_dec += prof_now() - t_m; n_blk += count; n_met += stop ? 1 : 0;)
+            if (lane == 0)
+                share_post(&rec->active, 0u);
+        }
+        sb += 64u;
+    }
+    if (lane == 0)
+        share_post(&sh->dec[w].active, 0u);
+    CORE_PROF(if (lane == 0 && r < 2) printf("core decay wave %u row %d: %d decays, %d blocks, %d ended early; walking %llu us, held back %llu us; scanned to %u\n", w, r, n_dec, n_blk, n_met,
+                                           t_dec / 100, t_hold / 100, sb);)
+}
+
+__global__ __launch_bounds__(512) void k_tp_core2(const TpArgs a) {
     __shared__ CoreShare sh_mem;
     LdsShare* const sh = (LdsShare*)&sh_mem;
     if (threadIdx.x == 0) {
         sh->w0_done = a.blk0, sh->w1_pos = a.blk0, sh->rb_seq = 0, sh->rb_ack = 0, sh->rb_blk = a.blk0, sh->rb_nf = 0.0f, sh->quit = 0;
         sh->fetch_next[0] = a.blk0, sh->fetch_next[1] = a.blk0;
+        for (int d = 0; d < 2; ++d)
+            sh->dec[d].start = 0xffffffffu, sh->dec[d].done = 0, sh->dec[d].active = 0;
     }
     __syncthreads();
+    if (threadIdx.x >= 256) {
+        // (waves go to the SIMDs of a CU in turn: waves 4 and 5 would share theirs with waves 0 and 1, which are the critical path
+        //  and never sleep; waves 6 and 7 share with the fetch waves, which mostly do)
+        if (a.core_decay && threadIdx.x >= 384) {
+            __builtin_amdgcn_s_setprio(2);
+            decay_wave(a, sh, threadIdx.x >= 448 ? 1u : 0u, threadIdx.x & 63);
+        }
+        return;
+    }
     if (threadIdx.x >= 64 && threadIdx.x < 128) {
         core_walk<true>(a, sh, threadIdx.x - 64);
         return;
@@ -883,7 +1152,7 @@ __global__ __launch_bounds__(256) void k_tp_core2(const TpArgs a) {
     const int lane = threadIdx.x & 63;
     const size_t bbase = static_cast<size_t>(r) * a.nblk;
     const uint32_t nblk = a.blk1;
-    if (threadIdx.x >= 128) {
+    if (threadIdx.x >= 128 && threadIdx.x < 256) {
         // ---- waves 2 and 3: the aggregates of every block into the rings, kFetchTrip blocks per trip and wave in turn, as far ahead of
         // wave 1 as the rings reach.  Entry b of opring is full_ at the start of block b, so the entries run to b = blk1 inclusive.
         const unsigned w = (threadIdx.x >= 192) ? 1u : 0u;
@@ -1544,6 +1813,7 @@ __device__ __forceinline__ void tp_block(TpLane& s, const ChanParams& p, const T
         }
     }
     if (!settled) {
+        CORE_PROF(++g_prof_unsettled;)
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {  // one copy of tp_chunk(); selects, not indexing, keep the samples in registers
             const float4 xk = (k == 0) ? q.x0 : (k == 1) ? q.x1 : (k == 2) ? q.x2 : q.x3;
@@ -1643,7 +1913,12 @@ __global__ __launch_bounds__(64) void k_tp_seg(const TpArgs a) {
         s.cur = s.next = SQ_CLOSED;
         s.delay = s.low = s.recent = 0;
         s.closed = kRecent;
-        s.agc = 0.5f;
+        // agcavgfast keeps its value while the squelch is closed, so what a transmission starts from is what the one before it left --
+        // possibly seconds back, far beyond any warm-up.  The open-edge bootstrap (0.9^100) and the samples after it shrink whatever
+        // the guess was wrong by, but only a guess within a fraction of a percent disappears under one ulp at once; 0.5 took ~3000
+        // open samples (six 512-step segments per transmission for the fix chains).  The channel's last committed value is such a
+        // guess whenever consecutive transmissions are about equally strong; it may be a call or two old, and it is only a guess.
+        s.agc = a.agc_hint ? a.st[row].agcavgfast : 0.5f;
     }
     const size_t rec_idx = static_cast<size_t>(r) * a.nseg + k;
     // The warm-up is one run over this call's arrays, preceded -- when it reaches back over the start of the call and the head is
@@ -1836,11 +2111,29 @@ __device__ __forceinline__ void rerun_chain(const TpArgs& a, const int r, const 
                 return;
         }
         const uint32_t s0 = k * a.L, s1 = min(s0 + a.L, a.nsteps);
+        if (kStateOnly && done == 0 && a.redo_listed) {
+            // The head of the chain starts from its true state here and now: run it for good (audio, record) instead of walking it
+            // for its end state and leaving the re-run to k_tp_redo.  With a good guess of agcavgfast (k_tp_seg) a chain is this one
+            // segment -- the one a transmission starts in -- and k_tp_redo finds its list empty.
+            const TpFsm S = canon(s);
+            const float s_agc = s.agc;
+            seg_reset(s);
+            CORE_PROF(const unsigned long long t_h = prof_now(); g_prof_unsettled = 0;)
+            tp_run<true>(s, p, a, r, row, magrow, s0, s1, s0 / kWaveBatch, base + k);
+            CORE_PROF(if (r == 0 && k < 200) printf("fix head r %d seg %u: %llu us, %d of 32 blocks through the sample path, start state %d end state %d\n", r, k, (prof_now() - t_h) / 100,
+                                                   g_prof_unsettled, S.cur, s.cur);)
+            rec_store(a, base + k, S, s_agc, s);
+            a.need[base + k] = 0;
+            seg_reset(s);
+            continue;
+        }
         if (kStateOnly) {
             int* __restrict__ ts = a.tstart + (base + k) * 8;
             ts[0] = s.cur, ts[1] = s.next, ts[2] = s.delay, ts[3] = s.low, ts[4] = s.recent, ts[5] = s.closed;
             ts[6] = __float_as_int(s.agc);
             a.need[base + k] = 2;
+            if (a.redo_listed)
+                a.redo[1 + atomicAdd(a.redo, 1)] = static_cast<int>(base + k);
             tp_run<false>(s, p, a, r, row, magrow, s0, s1, 0, base + k);
         } else {
             const TpFsm S = canon(s);
@@ -1882,20 +2175,20 @@ __device__ __forceinline__ void redo_segment(const TpArgs& a, const int r, const
     rec_store(a, base + k, S, s_agc, s);
 }
 
-// every segment a chain of k_tp_fix passed through, from its true start state, side by side
+// every segment a chain of k_tp_fix passed through, from its true start state, side by side: one segment per wave (a lane that
+// shares its wave with lanes at other points of their segments pays for their paths too), taken from the list the chains left
 __global__ __launch_bounds__(64) void k_tp_redo(const TpArgs a) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nsc = static_cast<int>(a.seg1 - a.seg0);
-    if (gid >= a.nrows * nsc)
-        return;
-    const int r = gid / nsc;
-    const uint32_t k = a.seg0 + static_cast<uint32_t>(gid - r * nsc);
-    const size_t base = static_cast<size_t>(r) * a.nseg;
-    if (a.need[base + k] != 2)
-        return;
-    const int row = a.rows[r];
-    const ChanParams p = a.cp[row % a.nch];
-    redo_segment(a, r, row, p, k);
+    const int count = a.redo[0];
+    for (int w = blockIdx.x; w < count; w += gridDim.x) {
+        if (threadIdx.x != 0)
+            continue;
+        const int idx = a.redo[1 + w];
+        const int r = idx / static_cast<int>(a.nseg);
+        const uint32_t k = static_cast<uint32_t>(idx - r * static_cast<int>(a.nseg));
+        const int row = a.rows[r];
+        const ChanParams p = a.cp[row % a.nch];
+        redo_segment(a, r, row, p, k);
+    }
 }
 
 // Everything the first scan / fix / redo round left open, settled by the row's own wave without further launches (a launch
@@ -2128,7 +2421,7 @@ hipError_t launch_tp_core(const TpArgs& a, hipStream_t s) {
     if (a.nrows == 0 || a.step1 <= a.step0)
         return hipSuccess;
     if (a.core_split)
-        TP_LAUNCH(k_tp_core2, a.nrows, 256);
+        TP_LAUNCH(k_tp_core2, a.nrows, 512);
     else
         TP_LAUNCH(k_tp_core, a.nrows, 64);
     return hipSuccess;
@@ -2172,8 +2465,15 @@ hipError_t launch_tp_rest(const TpArgs& a_in, hipStream_t s, hipEvent_t* marks) 
     const int lanes = a.nrows * static_cast<int>(a.seg1 - a.seg0);
     TP_LAUNCH(k_tp_scan, a.nrows, 64);
     TP_MARK(0);
+    {
+        hipError_t e__ = hipMemsetAsync(a.redo, 0, sizeof(int), s);
+        if (e__ != hipSuccess)
+            return e__;
+    }
+    a.redo_listed = 1;
     TP_LAUNCH(k_tp_fix, (lanes + 63) / 64, 64);
-    TP_LAUNCH(k_tp_redo, (lanes + 3) / 4, 4);
+    TP_LAUNCH(k_tp_redo, min(lanes, 2048), 64);
+    a.redo_listed = 0;  // (k_tp_settle's own rounds hand their members over through need[] alone)
     TP_MARK(1);
     TP_LAUNCH(k_tp_settle, a.nrows, 64);
     TP_LAUNCH(k_tp_finish, a.nrows, 64);

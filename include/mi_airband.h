@@ -270,6 +270,12 @@ enum {
     MI_OPT_PRE_WAVE = 14,     /* serial stage 2 with one channel per wave: a second wave per channel walks the squelch's pre-filter averages and
                                * noise floor over the call ahead of the channel's own wave (demod.hip, k_demod_pw).  -1 (default): up to 512
                                * rows (streams x channels), 0 never, 1 always */
+    MI_OPT_RESERVE_CUS = 15,  /* time-parallel path: the wide passes of a call (stage 1, aggregates, segment pass) keep off this many CUs, which stay
+                               * free for the core chains and the latency-bound tail kernels of the neighbouring calls (they need few waves but
+                               * most of a SIMD's registers each, and otherwise wait for a wide wave to retire).  -1 (default): 32 on handles of
+                               * up to 64 rows, 0 beyond; 0 never.  Takes effect only when the stream handed to mi_demod_process_device is not
+                               * the NULL stream (the restricted streams are blocking ones: hipExtStreamCreateWithCUMask); set before the first
+                               * time-parallel call.  The host-buffer entries use the handle's own stream and always qualify. */
     MI_OPT_LANE_FFT_JIT = 11  /* 1 (default): that kernel is compiled for the plan's own FFT nodes by hipRTC on first use (the code object is
                                * cached per (device, hop, masks) for the life of the process); 0, or hipRTC missing: the prebuilt full graph */
 };

@@ -230,3 +230,56 @@ uint64_t p3_rounds(const float* st, size_t nblk, uint64_t* hist, uint64_t* accep
     }
     return total;
 }
+
+/* p3_rounds with the dip runs walked by systolic passes: when a round ends at a lane and the lanes behind it look like steps below
+ * the floor by their (old) guesses (operand < guess), those L lanes are settled by L classical passes instead of L rounds.
+ * out[0] = rounds, out[1] = classical passes, out[2] = dip runs. */
+void p3_rounds_dips(const float* st, size_t nblk, uint64_t* out) {
+    uint32_t e[3] = {0, 0, 0};
+    int have = 0;
+    out[0] = out[1] = out[2] = 0;
+    for (size_t g0 = 0; g0 + 64 <= nblk; g0 += 64) {
+        size_t kk = 0;
+        while (kk < 64) {
+            const float nf = st[4 * (g0 + kk)];
+            const uint32_t nfb = fbits(nf), inc = fbits(nf + 1e-6f) - nfb;
+            uint32_t ee[3], guess[65];
+            for (int q = 0; q < 3; q++)
+                ee[q] = (have && e[q] + 1u - inc <= 2u) ? e[q] : inc;
+            guess[kk] = nfb;
+            for (size_t j = kk; j < 64; j++)
+                guess[j + 1] = guess[j] + ee[(g0 + j) % 3];
+            size_t j = kk;
+            uint32_t g = nfb;
+            for (;; j++) {
+                float gv;
+                memcpy(&gv, &g, 4);
+                const uint32_t ob = fbits(nf_step(gv, st[4 * (g0 + j) + 1]));
+                if (j + 1 >= 64 || ob != guess[j + 1])
+                    break;
+                g = ob;
+            }
+            for (size_t i = (j >= 2 ? j - 2 : 0); i <= j; i++)
+                e[(g0 + i) % 3] = fbits(st[4 * (g0 + i) + 3]) - fbits(st[4 * (g0 + i)]);
+            have = 1;
+            out[0]++;
+            kk = j + 1;
+            /* dip run behind the round's last lane, judged by the round's own guesses */
+            size_t L = 0;
+            while (kk + L < 64) {
+                float gv;
+                memcpy(&gv, &guess[kk + L], 4);
+                if (!(st[4 * (g0 + kk + L) + 1] < gv))
+                    break;
+                L++;
+            }
+            if (L) {
+                out[1] += L;
+                out[2]++;
+                for (size_t i = (kk + L >= 3 ? kk + L - 3 : 0); i < kk + L; i++)
+                    e[(g0 + i) % 3] = fbits(st[4 * (g0 + i) + 3]) - fbits(st[4 * (g0 + i)]);
+                kk += L;
+            }
+        }
+    }
+}

@@ -490,24 +490,32 @@ def test_consecutive_calls_overlap_with_early_input(pkg, monkeypatch, calls):
     d_iq = torch.zeros(pad, dtype=torch.uint8, device="cuda")
     d_iq[:iq.size] = torch.from_numpy(iq).cuda()
     torch.cuda.synchronize()
-    s = torch.cuda.current_stream().cuda_stream
-    d = pkg.Demod(dev, chans, nstreams=1, max_batches=max(calls))
-    d.set_option(pkg.OPT_EARLY_INPUT, 1)
-    outs, flags, done = [], [], 0
-    for k in calls:
-        pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
-        wo = torch.empty((1, len(chans), k * WAVE_BATCH), dtype=torch.float32, device="cuda")
-        ax = torch.empty((1, len(chans), k), dtype=torch.uint8, device="cuda")
-        d.process_device(d_iq.data_ptr() + pos, pad - pos, k, wo.data_ptr(), ax.data_ptr(), hip_stream=s)
-        outs.append(wo)
-        flags.append(ax)
-        done += k
-    torch.cuda.synchronize()
-    wo = torch.cat(outs, dim=2).cpu().numpy()
-    ax = torch.cat(flags, dim=2).cpu().numpy()
-    d.close()
-    assert_same(ax[0], oaxc, "axcindicate")
-    assert_same(wo[0], owo, "audio")
+    # On the NULL stream the wide passes run on the handle's plain streams; on any other stream on its CU-restricted twins
+    # (MI_OPT_RESERVE_CUS); a handle that is given both in turn changes sides between calls.
+    side = torch.cuda.Stream()
+    for streams in ("null", "side", "both"):
+        d = pkg.Demod(dev, chans, nstreams=1, max_batches=max(calls))
+        d.set_option(pkg.OPT_EARLY_INPUT, 1)
+        outs, flags, done = [], [], 0
+        for n, k in enumerate(calls):
+            pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+            wo = torch.empty((1, len(chans), k * WAVE_BATCH), dtype=torch.float32, device="cuda")
+            ax = torch.empty((1, len(chans), k), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()  # (the buffers exist before a call on another stream may write them)
+            use_side = streams == "side" or (streams == "both" and n % 2 == 1)
+            s = side.cuda_stream if use_side else torch.cuda.current_stream().cuda_stream
+            d.process_device(d_iq.data_ptr() + pos, pad - pos, k, wo.data_ptr(), ax.data_ptr(), hip_stream=s)
+            if streams == "both":
+                torch.cuda.synchronize()  # calls on different caller streams are the caller's to order
+            outs.append(wo)
+            flags.append(ax)
+            done += k
+        torch.cuda.synchronize()
+        wo = torch.cat(outs, dim=2).cpu().numpy()
+        ax = torch.cat(flags, dim=2).cpu().numpy()
+        d.close()
+        assert_same(ax[0], oaxc, f"axcindicate ({streams} stream)")
+        assert_same(wo[0], owo, f"audio ({streams} stream)")
 
 
 @pytest.mark.parametrize("spec_head,core_split,seg", [(1, 1, 512), (0, 1, 512), (1, 0, 512), (0, 0, 512), (1, 1, 2048), (1, 1, 4096)])
