@@ -31,7 +31,7 @@ def test_host_mirror_builds_and_links():
     _build()
     assert os.access(TOOL, os.X_OK)
     out = subprocess.run(["nm", "-D", "--undefined-only", TOOL], capture_output=True, text=True).stdout
-    for sym in ("mi_demod_create", "mi_demod_process", "mi_demod_bytes_consumed", "mi_demod_destroy"):
+    for sym in ("mi_demod_create", "mi_demod_prepare", "mi_demod_submit", "mi_demod_wait", "mi_demod_bytes_consumed", "mi_demod_destroy"):
         assert sym in out, f"the host mirror must go through the C ABI ({sym})"
 
 
