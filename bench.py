@@ -32,7 +32,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3  # same guide: peak fp32 vector
-PMC_PROFILE = "r02_pmc.csv"
+PMC_PROFILES = {"config2": "r03_pmc.csv", "config3": "r03_config3_pmc.csv", "config4": "r03_config4_pmc.csv", "am64": "r03_am64_pmc.csv"}
 SAMPLE_RATE = 2560000
 WAVE_BATCH = 2000
 AGC_EXTRA = 100
@@ -242,7 +242,9 @@ def traffic_of(traffic, name):
     """PMC bytes per launch of a bench kernel name; stage 1 runs as l64_entry (the plan-compiled lane-resident kernel),
     k_channelize9p or k_channelize<...> depending on the plan and the options."""
     b = name.split("#")[0]
-    for k in ((b, "l64_entry", b + "9p") if b == "k_channelize" else ((b, b + "2") if b == "k_tp_core" else (b,))):  # (k_tp_core2: the three-wave chain)
+    alias = {"k_channelize": ("k_channelize", "l64_entry", "k_channelize9p"), "k_tp_core": ("k_tp_core", "k_tp_core2"),  # (k_tp_core2: the split chain)
+             "k_demod": ("k_demod_pw", "k_demod")}                                                                    # (k_demod_pw: with the pre-filter wave)
+    for k in alias.get(b, (b,)):
         if k in traffic:
             return traffic[k]
     return None
@@ -346,13 +348,15 @@ def main():
         # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the bench):
         # only quoted when the launch geometry is the one that was profiled (default --seconds, default chunking).
         traffic, traffic_src = {}, None
-        pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
-        if os.path.exists(pmc) and res["nbat"] == 512 and args.workload == "config2" and not args.noise_only and "MI_AIRBAND_TP_CHUNKS" not in os.environ:
+        pmc_name = PMC_PROFILES.get(args.workload, "")
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
+        default_geometry = not args.seconds and not args.streams and not args.noise_only and "MI_AIRBAND_TP_CHUNKS" not in os.environ
+        if pmc_name and os.path.exists(pmc) and default_geometry:
             import csv
             for row in csv.DictReader(open(pmc)):
                 traffic[row["kernel"]] = int(row["hbm_bytes_per_launch"])
             sha = hashlib.sha1(open(pmc, "rb").read()).hexdigest()[:12]
-            traffic_src = (f"profiles/{PMC_PROFILE} (sha1 {sha}): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command "
+            traffic_src = (f"profiles/{pmc_name} (sha1 {sha}): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command "
                            f"(tools/make_profiles.sh), FETCH_SIZE x2 (gfx950); not re-measured inside this run")
         for name, k in kernels.items():
             k["traffic"] = traffic_of(traffic, name)

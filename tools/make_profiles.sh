@@ -4,25 +4,29 @@
 # command, the kernel traces of the config-3 / config-4 / am64 workloads and the SQ counter passes of stage 1 on am64.
 # The PMC passes force one chunk on every call (MI_AIRBAND_TP_CHUNKS=1): that is the geometry of every timed step of
 # the bench (only the first, isolated warm-up call of a run uses two chunks), so the per-launch means are exact.
-# Usage: tools/make_profiles.sh [round prefix, default r02] [stages: pmc bench kt kt3 kt4 ktam sq, default all]
+# Usage: tools/make_profiles.sh [round prefix, default r03] [stages: pmc bench kt kt3 kt4 ktam sq, default all]
 set -e
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
-R=${1:-r02}
-STAGES=${2:-"pmc bench kt kt3 kt4 ktam sq"}
+R=${1:-r03}
+STAGES=${2:-"pmc bench kt kt3 kt4 ktam sq vgpr"}
 O=gpurun_out
 mkdir -p $O
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 keep_stats() { find "$1" -name "*kernel_stats.csv" -exec cp {} "$2" \; ; rm -rf "$1"; }
 if has pmc; then
-  rm -rf $O/pmc_fetch $O/pmc_write
-  MI_AIRBAND_TP_CHUNKS=1 MI_AIRBAND_TP_RATIO=1.0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 > $O/pmc_fetch.log 2>&1
-  echo "pmc fetch done"
-  MI_AIRBAND_TP_CHUNKS=1 MI_AIRBAND_TP_RATIO=1.0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 > $O/pmc_write.log 2>&1
-  echo "pmc write done"
-  python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/${R}_pmc.csv > /dev/null
-  cp $O/${R}_pmc.csv profiles/${R}_pmc.csv
-  rm -rf $O/pmc_fetch $O/pmc_write
+  # headline workload + the three others: `traffic` of every bench line comes from these files (bench.py: PMC_PROFILES)
+  for wl in config2 config3 config4 am64; do
+    rm -rf $O/pmc_fetch $O/pmc_write
+    extra="--workload $wl --steps 2 --warmup 1 --cpu-seconds 0"
+    MI_AIRBAND_TP_CHUNKS=1 MI_AIRBAND_TP_RATIO=1.0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py $extra > $O/pmc_fetch_$wl.log 2>&1
+    MI_AIRBAND_TP_CHUNKS=1 MI_AIRBAND_TP_RATIO=1.0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py $extra > $O/pmc_write_$wl.log 2>&1
+    name=${R}_pmc.csv; [ $wl != config2 ] && name=${R}_${wl}_pmc.csv
+    python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/$name > /dev/null
+    cp $O/$name profiles/$name
+    rm -rf $O/pmc_fetch $O/pmc_write
+    echo "pmc $wl done"
+  done
 fi
 if has bench; then
   python3 bench.py > $O/final_bench.log 2>&1
@@ -54,5 +58,9 @@ if has sq; then
   python3 tools/sq_summary.py $O/${R}_am64_sq_counters.csv $O/sq1 $O/sq2
   rm -rf $O/sq1 $O/sq2
   echo "sq counters done"
+fi
+if has vgpr; then
+  python3 tools/vgpr_report.py $O/${R}_vgpr.csv
+  echo "vgpr report done"
 fi
 ls -la $O/${R}_*
