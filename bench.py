@@ -108,7 +108,10 @@ def run_workload(pkg, args, workload, steps, warmup, gather_mode, rank, world, l
     nbytes = ((nsteps + AGC_EXTRA) * hop + 2 * (1 << fft_log) + 255) // 256 * 256
     # the library's calls go to a stream of their own, not the NULL stream: its CU-restricted streams (MI_OPT_RESERVE_CUS) are blocking
     # ones and would synchronise with the NULL stream
-    stream = torch.cuda.Stream()
+    # (only where those streams are used -- plans of up to 64 rows on the time-parallel path: elsewhere a second user stream only takes a
+    # hardware queue away from the library's own, BENCH_STREAM=null|side forces one)
+    want_side = {"null": False, "side": True}.get(os.environ.get("BENCH_STREAM", ""), nstreams * nch <= 64 and workload in ("config2", "am64"))
+    stream = torch.cuda.Stream() if want_side else torch.cuda.current_stream()
     torch.cuda.set_stream(stream)
 
     # this rank's streams of the job (stream-major partition, the one the gloo test covers); their ids seed the generator

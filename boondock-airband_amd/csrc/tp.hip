@@ -2179,9 +2179,9 @@ __device__ __forceinline__ void redo_segment(const TpArgs& a, const int r, const
 // shares its wave with lanes at other points of their segments pays for their paths too), taken from the list the chains left
 __global__ __launch_bounds__(64) void k_tp_redo(const TpArgs a) {
     const int count = a.redo[0];
-    for (int w = blockIdx.x; w < count; w += gridDim.x) {
-        if (threadIdx.x != 0)
-            continue;
+    // blockDim.x segments per wave: 1 on plans of few rows (the re-runs are the critical path of the tail), 4 where hundreds of rows
+    // leave thousands of them (throughput: the wave pays for every path its lanes take, but four at a time)
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < count; w += gridDim.x * blockDim.x) {
         const int idx = a.redo[1 + w];
         const int r = idx / static_cast<int>(a.nseg);
         const uint32_t k = static_cast<uint32_t>(idx - r * static_cast<int>(a.nseg));
@@ -2472,7 +2472,10 @@ hipError_t launch_tp_rest(const TpArgs& a_in, hipStream_t s, hipEvent_t* marks) 
     }
     a.redo_listed = 1;
     TP_LAUNCH(k_tp_fix, (lanes + 63) / 64, 64);
-    TP_LAUNCH(k_tp_redo, min(lanes, 2048), 64);
+    if (a.nrows <= 64)
+        TP_LAUNCH(k_tp_redo, min(lanes, 2048), 1);
+    else
+        TP_LAUNCH(k_tp_redo, min((lanes + 3) / 4, 8192), 4);
     a.redo_listed = 0;  // (k_tp_settle's own rounds hand their members over through need[] alone)
     TP_MARK(1);
     TP_LAUNCH(k_tp_settle, a.nrows, 64);
