@@ -62,7 +62,9 @@ for seed in range(first, last):
     d_iq = torch.zeros(pad, dtype=torch.uint8, device="cuda")
     d_iq[:iq.size] = torch.from_numpy(iq).cuda()
     torch.cuda.synchronize()
-    s_ = torch.cuda.current_stream().cuda_stream
+    # (the NULL stream, or one of the caller's own: the wide passes then run on the CU-restricted streams, MI_OPT_RESERVE_CUS)
+    side_ = torch.cuda.Stream() if seed % 3 == 0 else None
+    s_ = side_.cuda_stream if side_ is not None else torch.cuda.current_stream().cuda_stream
     # (call sizes vary with the seed; every call has at least 8 batches, so all of them are time-parallel)
     sizes = [[8, 8], [16], [8, 8], [8, 8]][seed % 4] if nbat == 16 else [nbat]
     f = pkg.Demod(dev, chans, max_batches=max(sizes))
