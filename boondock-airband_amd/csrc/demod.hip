@@ -24,6 +24,27 @@ enum : int { SQ_CLOSED = 0, SQ_OPENING = 1, SQ_CLOSING = 2, SQ_LOW_SIGNAL_ABORT 
 constexpr int kOpenDelay = 197, kCloseDelay = 197, kLowSignalAbort = 88;  // squelch.cpp:49-51
 constexpr uint32_t kRecentSampleSize = 1000, kFlapOpensThreshold = 3;    // squelch.cpp:62-63
 
+// ---- the audio wave's mailbox (k_demod_pw, NFM channels) ----
+// The channel wave (FSM, filter) posts, in the order of the steps: the filtered I/Q of every step whose audio is processed
+// (should_process_audio(): OPEN or CLOSING) as BLOCKs of 1..64 consecutive steps, the CTCSS resets (a transition to CLOSED),
+// the ends of the WAVE_BATCHes, and QUIT.  The audio wave consumes them in that order, so what it computes is the serial loop's
+// audio: it owns pr / pj / agcavgfast / prev_waveout, the notch filter, both CTCSS detector sets and their counters, the output
+// gate, axcindicate and the audio / raw-I/Q stores of those steps.  Nothing flows back except the final state at QUIT.
+constexpr unsigned kTokRing = 256;  // steps in flight (a power of two, >= 2 blocks)
+constexpr unsigned kDescRing = 32;
+enum : unsigned { AUX_BLOCK = 1, AUX_RESET = 2, AUX_BATCH = 3, AUX_QUIT = 4 };
+struct AuxShare {
+    float tk_re[kTokRing], tk_im[kTokRing];
+    unsigned d_word[kDescRing];  // type | n << 8
+    unsigned d_arg[kDescRing];   // BLOCK: the first step's index; BATCH: the batch's index
+    unsigned d_head;             // descriptors posted (channel wave)
+    unsigned d_tail;             // descriptors consumed (audio wave)
+    unsigned tk_tail;            // tokens consumed
+    unsigned done;               // the audio wave has stored its state after QUIT
+    unsigned fin[32];            // ... the part of ChanState it owns
+};
+typedef __attribute__((address_space(3))) AuxShare LdsAux;
+
 struct Ctx {
     ChanState s;
     ChanParams p;  // by value: registers, not a global load per use
@@ -39,6 +60,12 @@ struct Ctx {
     int lane;
     float gf_c, gf_q1, gf_q2;  // fast set, detector `lane`
     float gs_c, gs_q1, gs_q2;  // slow set, detector `lane`
+    // k_demod_pw, NFM channels: everything that hears the demodulated audio (discriminator, de-emphasis, CTCSS, gate, notch, the
+    // output stores) belongs to the audio wave; this wave posts the filtered I/Q of the steps whose audio is processed (AuxShare)
+    bool split;
+    LdsAux* aux;
+    unsigned tk_head, d_head;  // tokens / descriptors posted so far
+    unsigned* timeouts;
 };
 
 __device__ __forceinline__ float lane_read(const float v, const int lane) {
@@ -96,9 +123,14 @@ __device__ __forceinline__ void set_state(Ctx& c, int update) {  // squelch.cpp:
     c.s.next_state = update;
 }
 
+__device__ __forceinline__ void aux_post(Ctx& c, unsigned type, unsigned n, unsigned arg, float re, float im);
 __device__ __forceinline__ void ctcss_reset(Ctx& c) {  // CTCSS::reset on both detectors, ctcss.cpp:165-172
     if (!c.p.ctcss_enabled)
         return;
+    if (c.split) {  // the detectors live in the audio wave: the reset takes its place in the stream of its work
+        aux_post(c, 2u /* AUX_RESET */, 0u, 0u, 0.0f, 0.0f);
+        return;
+    }
     if (c.uni) {
         c.gf_q1 = c.gf_q2 = c.gs_q1 = c.gs_q2 = 0.0f;
     } else {
@@ -456,6 +488,42 @@ __device__ __forceinline__ bool pre_wait(LdsPre* pre, const int lane, const uint
     return true;
 }
 
+typedef __attribute__((address_space(3))) volatile unsigned aux_vu32;
+typedef __attribute__((address_space(3))) volatile float aux_vf32;
+__device__ __forceinline__ unsigned aux_peek(const __attribute__((address_space(3))) unsigned* p) {
+    return __builtin_amdgcn_readfirstlane(*(const aux_vu32*)p);
+}
+// channel wave: one descriptor, with n tokens (lane m < n holds step arg + m; n == 1 from the sample loop: wave-uniform values)
+__device__ __forceinline__ void aux_post(Ctx& c, const unsigned type, const unsigned n, const unsigned arg, const float re, const float im) {
+    LdsAux* const x = c.aux;
+    for (unsigned spin = 0;; ++spin) {  // room in both rings (the audio wave is the faster one: normally no wait)
+        const unsigned tt = aux_peek(&x->tk_tail), dt = aux_peek(&x->d_tail);
+        if (c.tk_head + n - tt <= kTokRing && c.d_head + 1u - dt <= kDescRing)
+            break;
+        __builtin_amdgcn_s_sleep(1);
+        if (spin > 4u * kPreSpin) {  // (the audio wave is gone: counted, asserted 0 by the tests)
+            if (c.lane == 0 && c.timeouts)
+                atomicAdd(c.timeouts, 1u);
+            break;
+        }
+    }
+    if (static_cast<unsigned>(c.lane) < n) {
+        const unsigned at = (c.tk_head + static_cast<unsigned>(c.lane)) & (kTokRing - 1u);
+        *(aux_vf32*)&x->tk_re[at] = re;
+        *(aux_vf32*)&x->tk_im[at] = im;
+    }
+    if (c.lane == 0) {
+        *(aux_vu32*)&x->d_word[c.d_head & (kDescRing - 1u)] = type | (n << 8);
+        *(aux_vu32*)&x->d_arg[c.d_head & (kDescRing - 1u)] = arg;
+    }
+    // a wave's LDS operations execute in order: the data before the mark (see pre_wave)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    c.tk_head += n;
+    c.d_head += 1u;
+    if (c.lane == 0)
+        *(aux_vu32*)&x->d_head = c.d_head;
+}
+
 struct BlockIo {
 #ifdef MI_BLOCK_PROF
     unsigned long long prof[8];
@@ -680,7 +748,8 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     // audio (rtl_airband.cpp:571-609)
     float d = 0.0f;  // the sample handed to process_audio_sample
     float G = 0.0f;  // agcavgfast after step m
-    if (do_audio) {
+    const bool own_audio = do_audio && !c.split;  // (split: the audio wave's, from the filtered I/Q posted at the commit)
+    if (own_audio) {
         if (P.modulation == MI_MOD_AM) {
             const bool upd = xf > level;
             const float bA = xf * 0.005f;
@@ -733,7 +802,7 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
 #endif
 
     // output gate (rtl_airband.cpp:612-641); is_open() cannot change inside the block (no detector window ends in it)
-    const bool gate = do_audio && (!P.ctcss_enabled || (s.cs_enough ? (s.cs_has_tone != 0) : (s.cf_has_tone != 0)));
+    const bool gate = own_audio && (!P.ctcss_enabled || (s.cs_enough ? (s.cs_has_tone != 0) : (s.cf_has_tone != 0)));
     float out = 0.0f;
     if (gate) {
         out = d;
@@ -774,13 +843,17 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
             h = h >= kSquelchRing ? h - kSquelchRing : h;
             c.ring[h] = C * 0.9f;
         }
-        const uint32_t v = kAgcExtra + i0 + lane;
-        float* dst = (v < io.n) ? io.wmain + v : io.carry + (v - io.n);
-        *dst = out;
-        if (io.iqo)
-            io.iqo[i0 + lane] = gate ? make_float2(re, im) : make_float2(0.0f, 0.0f);
+        if (!(do_audio && c.split)) {
+            const uint32_t v = kAgcExtra + i0 + lane;
+            float* dst = (v < io.n) ? io.wmain + v : io.carry + (v - io.n);
+            *dst = out;
+            if (io.iqo)
+                io.iqo[i0 + lane] = gate ? make_float2(re, im) : make_float2(0.0f, 0.0f);
+        }
     }
-    if (do_audio && P.ctcss_enabled) {  // Squelch::process_audio_sample -> CTCSS::process_audio_sample (ctcss.cpp:124-135)
+    if (do_audio && c.split)
+        aux_post(c, AUX_BLOCK, static_cast<unsigned>(kc), i0, re, im);
+    if (own_audio && P.ctcss_enabled) {  // Squelch::process_audio_sample -> CTCSS::process_audio_sample (ctcss.cpp:124-135)
         const bool fast_too = !s.cs_enough;
         for (int m = 0; m < kc; m += 4) {  // kc is a multiple of 4
 #pragma unroll
@@ -838,7 +911,7 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
             s.using_post_filter = 1;
         }
     }
-    if (do_audio) {
+    if (own_audio) {
         s.agcavgfast = lane_read(G, last);
         if (P.modulation != MI_MOD_AM) {
             s.pr = lane_read(re, last);
@@ -854,7 +927,7 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
 // the compiler's uniformity analysis sees a row that depends on blockIdx alone: the channel state then sits in scalar
 // registers where it can, the state machine's integer work runs on the scalar unit and its branches are scalar branches.
 template <bool kUni, bool kPre>
-__device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
+__device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsAux* aux) {
     bool pre_on = kPre;  // the pre-filter wave is there and delivering (k_demod_pw)
     const int rows = a.nstreams * a.nch;
     constexpr bool uni = kUni;
@@ -869,6 +942,10 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
     c.s = a.st[row];
     c.p = a.cp[ch];
     const ChanParams& P = c.p;
+    c.split = kPre && a.audio_wave && P.modulation != MI_MOD_AM;  // (the audio wave decides the same way)
+    c.aux = aux;
+    c.tk_head = c.d_head = 0;
+    c.timeouts = a.pre_timeouts;
     c.ring = a.sq_ring + static_cast<size_t>(row) * kSquelchRing;
     c.cc_fast = c.cc_slow = nullptr;
     c.cq_fast = c.cq_slow = nullptr;
@@ -877,7 +954,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
         c.cc_slow = c.cc_fast + kMaxTones;
         c.cq_fast = a.ctcss_q + (static_cast<size_t>(stream) * a.n_ctcss_rows + P.ctcss_row) * 4 * kMaxTones;
         c.cq_slow = c.cq_fast + 2 * kMaxTones;
-        if (uni) {  // detector `lane` of each set lives in this lane's registers for the whole call
+        if (uni && !c.split) {  // detector `lane` of each set lives in this lane's registers for the whole call
             if (c.lane < P.ctcss_fast_ndet)
                 c.gf_c = c.cc_fast[c.lane], c.gf_q1 = c.cq_fast[c.lane], c.gf_q2 = c.cq_fast[kMaxTones + c.lane];
             if (c.lane < P.ctcss_slow_ndet)
@@ -902,6 +979,20 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
     const float ampfactor = P.ampfactor;
     bool batch_open = false;
     uint32_t in_batch = 0, batch = 0;
+    // the end of a WAVE_BATCH: axcindicate and active_counter (rtl_airband.cpp:523,628,667-669) -- the audio wave's where it judges is_open()
+#define MI_END_BATCH()                                                                                                 \
+    do {                                                                                                               \
+        if (c.split) {                                                                                                 \
+            aux_post(c, AUX_BATCH, 0u, batch, 0.0f, 0.0f);                                                             \
+        } else {                                                                                                       \
+            a.axc[static_cast<size_t>(row) * a.axc_stride + batch] = batch_open ? MI_SIGNAL : MI_NO_SIGNAL;           \
+            if (batch_open)                                                                                            \
+                c.s.active_counter++;                                                                                  \
+        }                                                                                                              \
+        batch_open = false;                                                                                            \
+        in_batch = 0;                                                                                                  \
+        batch++;                                                                                                       \
+    } while (0)
 
     // Memory traffic is batched four steps at a time: the inputs of steps i0+4 .. i0+7 are requested (16 B per row and
     // plane) while steps i0 .. i0+3 run, and the four outputs leave as one 16-B store.  A load's wait also waits for every
@@ -960,7 +1051,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
                   }
                   if (st == SQ_OPEN || st == SQ_CLOSING) {
                       ok = ok && upf == (lpz ? 1 : 0);
-                      if (P.ctcss_enabled) {  // a detector window's last sample is taken by the sample loop
+                      if (P.ctcss_enabled && !c.split) {  // a detector window's last sample is taken by the sample loop
                           kmax = min(kmax, P.ctcss_slow_window - 1 - __builtin_amdgcn_readfirstlane(c.s.cs_count));
                           if (!c.s.cs_enough)
                               kmax = min(kmax, P.ctcss_fast_window - 1 - __builtin_amdgcn_readfirstlane(c.s.cf_count));
@@ -973,14 +1064,8 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
                       const int kc = steady_block<kPre>(c, a, bio, gi * 4, kmax, batch_open, pre, pre_on);
                       if (kc > 0) {
                           in_batch += static_cast<uint32_t>(kc);
-                          if (in_batch == kWaveBatch) {
-                              a.axc[static_cast<size_t>(row) * a.axc_stride + batch] = batch_open ? MI_SIGNAL : MI_NO_SIGNAL;
-                              if (batch_open)
-                                  c.s.active_counter++;
-                              batch_open = false;
-                              in_batch = 0;
-                              batch++;
-                          }
+                          if (in_batch == kWaveBatch)
+                              MI_END_BATCH();
                           gi += static_cast<uint32_t>(kc / 4);
                           stale = true;  // the group fetched ahead is behind us now
                           if (kc < 8)
@@ -1035,6 +1120,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
           const float gre[4] = {cz0.x, cz0.z, cz1.x, cz1.z}, gim[4] = {cz0.y, cz0.w, cz1.y, cz1.w};
           float pend[4] = {0.f, 0.f, 0.f, 0.f};  // waveout of the group, stored together at its end
           int flushed = 0;                        // outputs [0, flushed) already went out one by one (a fade rewrote them)
+          unsigned posted = 0;                    // bit m: step m went to the audio wave, which stores its outputs
           // Idle channel: CLOSED, and no sample of the group lifts pre_filter_.capped_ to the squelch level.  Then the four
           // steps only move the averages, the noise floor, the closed-sample counter and the squelch ring (squelch.cpp:
           // 442-449, 195-246 with every branch not taken); tried on copies, committed only if it held for all four.
@@ -1094,14 +1180,8 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
                       z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
                   }
                   in_batch += 4;  // WAVE_BATCH is a multiple of 4: a batch ends at a group end
-                  if (in_batch == kWaveBatch) {
-                      a.axc[static_cast<size_t>(row) * a.axc_stride + batch] = batch_open ? MI_SIGNAL : MI_NO_SIGNAL;
-                      if (batch_open)
-                          c.s.active_counter++;
-                      batch_open = false;
-                      in_batch = 0;
-                      batch++;
-                  }
+                  if (in_batch == kWaveBatch)
+                      MI_END_BATCH();
               }
           }
           if (!idle) {
@@ -1179,6 +1259,9 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
                         wout *= 0.85f;
                         c.s.agcavgfast *= 1.15f;
                     }
+                } else if (c.split) {  // NFM: the audio wave's (rtl_airband.cpp:587-641 from the filtered I/Q)
+                    aux_post(c, AUX_BLOCK, 1u, i, re, im);
+                    posted |= 1u << m;
                 } else {  // NFM, rtl_airband.cpp:587-604
                     if (!a.fm_quadri) {
                         const float nbj = -c.s.pj;  // polar_disc_fast: multiply(ar, aj, br, -bj)
@@ -1195,10 +1278,11 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
                     wout = wout * P.one_minus_alpha + c.s.prev_waveout * P.alpha;
                     c.s.prev_waveout = wout;
                 }
-                process_audio(c, wout);  // rtl_airband.cpp:608
+                if (!c.split)
+                    process_audio(c, wout);  // rtl_airband.cpp:608
             }
 
-            if (is_open(c)) {  // rtl_airband.cpp:612-641
+            if (!c.split && is_open(c)) {  // rtl_airband.cpp:612-641
                 if (P.notch_enabled) {  // NotchFilter::apply, filters.cpp:50-64
                     ChanState& s = c.s;
                     s.notch_x[0] = s.notch_x[1];
@@ -1222,29 +1306,23 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
                     iqo[i] = make_float2(re, im);
             } else {
                 wout = 0.0f;
-                if (iqo)
+                if (iqo && !((posted >> m) & 1u))
                     iqo[i] = make_float2(0.0f, 0.0f);
             }
             pend[m] = wout;
 
-            if (++in_batch == kWaveBatch) {  // rtl_airband.cpp:523,628,667-669
-                a.axc[static_cast<size_t>(row) * a.axc_stride + batch] = batch_open ? MI_SIGNAL : MI_NO_SIGNAL;
-                if (batch_open)
-                    c.s.active_counter++;
-                batch_open = false;
-                in_batch = 0;
-                batch++;
-            }
+            if (++in_batch == kWaveBatch)  // rtl_airband.cpp:523,628,667-669
+                MI_END_BATCH();
           }
           }
-          if (flushed == 0) {
+          if (flushed == 0 && posted == 0) {
               const uint32_t v = kAgcExtra + i0;
               float* dst = (v < n) ? wmain + v : carry + (v - n);
               *reinterpret_cast<float4*>(dst) = make_float4(pend[0], pend[1], pend[2], pend[3]);
           } else {
 #pragma unroll
               for (int k = 0; k < 4; ++k)
-                  if (k >= flushed)
+                  if (k >= flushed && !((posted >> k) & 1u))
                       W(kAgcExtra + i0 + k) = pend[k];
           }
         }
@@ -1270,7 +1348,30 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
             zh[v] = zw[n + v];
     }
 
-    if (uni && P.ctcss_enabled) {
+    if (c.split) {
+        // the audio wave finishes what it was sent, stores the detectors' state and hands back the part of ChanState it owns
+        aux_post(c, AUX_QUIT, 0u, 0u, 0.0f, 0.0f);
+        for (unsigned spin = 0; aux_peek(&aux->done) == 0u; ++spin) {
+            __builtin_amdgcn_s_sleep(2);
+            if (spin > 4u * kPreSpin) {
+                if (c.lane == 0 && c.timeouts)
+                    atomicAdd(c.timeouts, 1u);
+                break;
+            }
+        }
+        asm volatile("" ::: "memory");
+        auto fw = [&](const int k) { return aux_peek(&aux->fin[k]); };
+        auto ff = [&](const int k) { return __uint_as_float(fw(k)); };
+        auto f64 = [&](const int k) { return static_cast<uint64_t>(fw(k)) | (static_cast<uint64_t>(fw(k + 1)) << 32); };
+        ChanState& s = c.s;
+        s.agcavgfast = ff(0), s.pr = ff(1), s.pj = ff(2), s.prev_waveout = ff(3);
+        s.notch_x[0] = ff(4), s.notch_x[1] = ff(5), s.notch_x[2] = ff(6);
+        s.notch_y[0] = ff(7), s.notch_y[1] = ff(8), s.notch_y[2] = ff(9);
+        s.cf_enough = static_cast<int32_t>(fw(10)), s.cf_count = static_cast<int32_t>(fw(11)), s.cf_has_tone = static_cast<int32_t>(fw(12));
+        s.cs_enough = static_cast<int32_t>(fw(13)), s.cs_count = static_cast<int32_t>(fw(14)), s.cs_has_tone = static_cast<int32_t>(fw(15));
+        s.cf_found = f64(16), s.cf_not_found = f64(18), s.cs_found = f64(20), s.cs_not_found = f64(22);
+        s.active_counter = f64(24);
+    } else if (uni && P.ctcss_enabled) {
         if (c.lane < P.ctcss_fast_ndet)
             c.cq_fast[c.lane] = c.gf_q1, c.cq_fast[kMaxTones + c.lane] = c.gf_q2;
         if (c.lane < P.ctcss_slow_ndet)
@@ -1305,7 +1406,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre) {
 
 template <bool kUni>
 __global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
-    demod_body<kUni, false>(a, nullptr);
+    demod_body<kUni, false>(a, nullptr, nullptr);
 }
 
 // The pre-filter wave of k_demod_pw: the recurrence of steady_block()'s first phase, block after block over the whole call.
@@ -1372,18 +1473,250 @@ __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const 
     }
 }
 
-// One channel per workgroup of two waves: the channel itself (as k_demod<true>) and the pre-filter wave ahead of it.
-__global__ __launch_bounds__(128) void k_demod_pw(const DemodArgs a) {
-    __shared__ PreShare sh_mem;
-    LdsPre* const pre = (LdsPre*)&sh_mem;
-    if (threadIdx.x == 0)
+// The audio wave of k_demod_pw (NFM channels): rtl_airband.cpp:587-641 and Squelch::process_audio_sample for the steps the channel
+// wave posts, in its order.  A BLOCK of n steps is taken in units that end short of a CTCSS detector window's last sample -- within
+// a unit is_open() cannot change -- as steady_block() does: step m in lane m, every recurrence a systolic chain; the sample that ends
+// a window is a unit of its own and goes through ctcss_process_lanes() like a step of the sample loop.  The same IEEE operations in
+// the same order on the same operands as there.
+__device__ __forceinline__ void audio_wave(const DemodArgs& a, LdsAux* x, const int lane) {
+    const int row = static_cast<int>(blockIdx.x);
+    const int stream = row / a.nch, ch = row - stream * a.nch;
+    const ChanParams P = a.cp[ch];
+    if (!a.audio_wave || P.modulation == MI_MOD_AM)
+        return;  // (the channel wave decides the same way and keeps everything)
+    const ChanState& s0 = a.st[row];
+    float agc = s0.agcavgfast, pr = s0.pr, pj = s0.pj, pw = s0.prev_waveout;
+    float nx0 = s0.notch_x[0], nx1 = s0.notch_x[1], nx2 = s0.notch_x[2];
+    float ny0 = s0.notch_y[0], ny1 = s0.notch_y[1], ny2 = s0.notch_y[2];
+    int cf_enough = s0.cf_enough, cf_count = s0.cf_count, cf_has_tone = s0.cf_has_tone;
+    int cs_enough = s0.cs_enough, cs_count = s0.cs_count, cs_has_tone = s0.cs_has_tone;
+    uint64_t cf_found = s0.cf_found, cf_not_found = s0.cf_not_found, cs_found = s0.cs_found, cs_not_found = s0.cs_not_found;
+    uint64_t active = s0.active_counter;
+    float gf_c = 0.0f, gf_q1 = 0.0f, gf_q2 = 0.0f, gs_c = 0.0f, gs_q1 = 0.0f, gs_q2 = 0.0f;
+    float* cq_fast = nullptr;
+    float* cq_slow = nullptr;
+    if (P.ctcss_enabled) {
+        const float* cc_fast = a.ctcss_coeff + static_cast<size_t>(P.ctcss_row) * 2 * kMaxTones;
+        const float* cc_slow = cc_fast + kMaxTones;
+        cq_fast = a.ctcss_q + (static_cast<size_t>(stream) * a.n_ctcss_rows + P.ctcss_row) * 4 * kMaxTones;
+        cq_slow = cq_fast + 2 * kMaxTones;
+        if (lane < P.ctcss_fast_ndet)
+            gf_c = cc_fast[lane], gf_q1 = cq_fast[lane], gf_q2 = cq_fast[kMaxTones + lane];
+        if (lane < P.ctcss_slow_ndet)
+            gs_c = cc_slow[lane], gs_q1 = cq_slow[lane], gs_q2 = cq_slow[kMaxTones + lane];
+    }
+    float* __restrict__ wmain = a.wmain + static_cast<size_t>(row) * a.wmain_stride;
+    float* __restrict__ carry = a.carry + static_cast<size_t>(row) * kAgcExtra;
+    float2* __restrict__ iqo = (a.iq_out && P.has_iq_outputs) ? a.iq_out + static_cast<size_t>(row) * a.iq_out_stride : nullptr;
+    const uint32_t nsteps = a.nsteps;
+    bool batch_open = false;
+    unsigned d_tail = 0, tk_pos = 0;
+
+    for (;;) {
+        for (unsigned spin = 0; aux_peek(&x->d_head) == d_tail; ++spin) {
+            __builtin_amdgcn_s_sleep(4);
+            if (spin > 16u * kPreSpin)
+                return;  // (the channel wave is gone)
+        }
+        asm volatile("" ::: "memory");
+        const unsigned word = aux_peek(&x->d_word[d_tail & (kDescRing - 1u)]);
+        const unsigned arg = aux_peek(&x->d_arg[d_tail & (kDescRing - 1u)]);
+        const unsigned type = word & 0xffu;
+        if (type == AUX_BLOCK) {
+            int remaining = static_cast<int>(word >> 8);
+            unsigned off = 0;
+            while (remaining > 0) {
+                int lim = 64;  // steps before the one that ends a detector window
+                if (P.ctcss_enabled) {
+                    lim = P.ctcss_slow_window - 1 - cs_count;
+                    if (!cs_enough)
+                        lim = min(lim, P.ctcss_fast_window - 1 - cf_count);
+                }
+                const bool ends_window = lim <= 0;
+                const int n = ends_window ? 1 : min(remaining, lim);
+                const unsigned at = (tk_pos + off + static_cast<unsigned>(lane)) & (kTokRing - 1u);
+                const float re = *(aux_vf32*)&x->tk_re[at], im = *(aux_vf32*)&x->tk_im[at];
+                // discriminator, DC block, de-emphasis (rtl_airband.cpp:587-604)
+                const float prr = shr1(re, pr), pjj = shr1(im, pj);
+                float w;
+                if (!a.fm_quadri) {
+                    const float nbj = -pjj;  // polar_disc_fast: multiply(ar, aj, br, -bj)
+                    const float cr = re * prr - im * nbj;
+                    const float cj = im * prr + re * nbj;
+                    w = static_cast<float>(static_cast<double>(fast_atan2(cj, cr)) * M_1_PI);
+                } else {
+                    w = static_cast<float>(static_cast<double>((prr * im - re * pjj) / (re * re + im * im + 1.0f)) * M_1_PI);
+                }
+                const float bN = w * 0.005f;
+                float G = 0.0f, Gp = agc;
+                MI_PASSES(0, n, {
+                    Gp = shr1(G, Gp);
+                    G = Gp * 0.995f + bN;
+                })
+                const float e = (w - G) * P.one_minus_alpha;
+                float D = 0.0f, Dp = pw;
+                MI_PASSES(0, n, {
+                    Dp = shr1(D, Dp);
+                    D = e + Dp * P.alpha;
+                })
+                const float d = D;
+                const int last = n - 1;
+                // Squelch::process_audio_sample (squelch.cpp:278-295; the state is OPEN or CLOSING: never CLOSED)
+                if (P.ctcss_enabled) {
+                    if (ends_window) {
+                        const float smp = lane_read(d, 0);
+                        ctcss_process_lanes(gs_c, gs_q1, gs_q2, P.ctcss_slow_ndet, P.ctcss_slow_window, cs_count, cs_enough, cs_has_tone, cs_found, cs_not_found, smp);
+                        if (!cs_enough)
+                            ctcss_process_lanes(gf_c, gf_q1, gf_q2, P.ctcss_fast_ndet, P.ctcss_fast_window, cf_count, cf_enough, cf_has_tone, cf_found,
+                                                cf_not_found, smp);
+                    } else {
+                        const bool fast_too = !cs_enough;
+                        int m = 0;
+                        for (; m + 4 <= n; m += 4) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float smp = lane_read(d, m + u);
+                                const float q0 = gs_c * gs_q1 - gs_q2 + smp;
+                                gs_q2 = gs_q1;
+                                gs_q1 = q0;
+                                if (fast_too) {
+                                    const float f0 = gf_c * gf_q1 - gf_q2 + smp;
+                                    gf_q2 = gf_q1;
+                                    gf_q1 = f0;
+                                }
+                            }
+                        }
+                        for (; m < n; ++m) {
+                            const float smp = lane_read(d, m);
+                            const float q0 = gs_c * gs_q1 - gs_q2 + smp;
+                            gs_q2 = gs_q1;
+                            gs_q1 = q0;
+                            if (fast_too) {
+                                const float f0 = gf_c * gf_q1 - gf_q2 + smp;
+                                gf_q2 = gf_q1;
+                                gf_q1 = f0;
+                            }
+                        }
+                        cs_count += n;
+                        if (fast_too)
+                            cf_count += n;
+                    }
+                }
+                // output gate (rtl_airband.cpp:612-641)
+                const bool gate = !P.ctcss_enabled || (cs_enough ? (cs_has_tone != 0) : (cf_has_tone != 0));
+                float out = 0.0f;
+                if (gate) {
+                    out = d;
+                    if (P.notch_enabled) {  // NotchFilter::apply, filters.cpp:50-64
+                        const float u1 = shr1(d, nx2);
+                        const float u2 = shr1(u1, nx1);
+                        const float B = P.notch_d0 * d - P.notch_d1 * u1 + P.notch_d0 * u2;
+                        float Y = 0.0f, Y1 = ny2, Y2 = ny1;
+                        MI_PASSES(0, n, {
+                            Y2 = shr1(Y1, Y2);
+                            Y1 = shr1(Y, Y1);
+                            Y = B + P.notch_d1 * Y1 - P.notch_d2 * Y2;
+                        })
+                        out = Y;
+                        // the last three inputs / outputs, of this unit and of what came before it
+                        const float ox1 = nx1, ox2 = nx2, oy1 = ny1, oy2 = ny2;
+                        nx0 = n >= 3 ? lane_read(d, max(last - 2, 0)) : (n == 2 ? ox2 : ox1);
+                        nx1 = n >= 2 ? lane_read(d, max(last - 1, 0)) : ox2;
+                        nx2 = lane_read(d, last);
+                        ny0 = n >= 3 ? lane_read(Y, max(last - 2, 0)) : (n == 2 ? oy2 : oy1);
+                        ny1 = n >= 2 ? lane_read(Y, max(last - 1, 0)) : oy2;
+                        ny2 = lane_read(Y, last);
+                    }
+                    out *= P.ampfactor;
+                    if (out != out)
+                        out = 0.0f;
+                    else if (out > 1.0f)
+                        out = 1.0f;
+                    else if (out < -1.0f)
+                        out = -1.0f;
+                    batch_open = true;
+                }
+                if (lane < n) {
+                    const uint32_t i = arg + off + static_cast<uint32_t>(lane);
+                    const uint32_t v = kAgcExtra + i;
+                    float* dst = (v < nsteps) ? wmain + v : carry + (v - nsteps);
+                    *dst = out;
+                    if (iqo)
+                        iqo[i] = gate ? make_float2(re, im) : make_float2(0.0f, 0.0f);
+                }
+                agc = lane_read(G, last);
+                pr = lane_read(re, last);
+                pj = lane_read(im, last);
+                pw = lane_read(d, last);
+                off += static_cast<unsigned>(n);
+                remaining -= n;
+            }
+            tk_pos += word >> 8;
+            if (lane == 0)
+                *(aux_vu32*)&x->tk_tail = tk_pos;
+        } else if (type == AUX_RESET) {  // ctcss_reset()
+            gf_q1 = gf_q2 = gs_q1 = gs_q2 = 0.0f;
+            cf_enough = cf_count = cf_has_tone = 0;
+            cs_enough = cs_count = cs_has_tone = 0;
+        } else if (type == AUX_BATCH) {
+            if (lane == 0)
+                a.axc[static_cast<size_t>(row) * a.axc_stride + arg] = batch_open ? MI_SIGNAL : MI_NO_SIGNAL;
+            if (batch_open)
+                active++;
+            batch_open = false;
+        } else {  // AUX_QUIT
+            break;
+        }
+        ++d_tail;
+        if (lane == 0)
+            *(aux_vu32*)&x->d_tail = d_tail;
+    }
+    if (P.ctcss_enabled) {
+        if (lane < P.ctcss_fast_ndet)
+            cq_fast[lane] = gf_q1, cq_fast[kMaxTones + lane] = gf_q2;
+        if (lane < P.ctcss_slow_ndet)
+            cq_slow[lane] = gs_q1, cq_slow[kMaxTones + lane] = gs_q2;
+    }
+    if (lane == 0) {
+        auto pf = [&](const int k, const float v) { *(aux_vu32*)&x->fin[k] = __float_as_uint(v); };
+        auto pu = [&](const int k, const unsigned v) { *(aux_vu32*)&x->fin[k] = v; };
+        auto p64 = [&](const int k, const uint64_t v) { pu(k, static_cast<unsigned>(v)), pu(k + 1, static_cast<unsigned>(v >> 32)); };
+        pf(0, agc), pf(1, pr), pf(2, pj), pf(3, pw);
+        pf(4, nx0), pf(5, nx1), pf(6, nx2), pf(7, ny0), pf(8, ny1), pf(9, ny2);
+        pu(10, static_cast<unsigned>(cf_enough)), pu(11, static_cast<unsigned>(cf_count)), pu(12, static_cast<unsigned>(cf_has_tone));
+        pu(13, static_cast<unsigned>(cs_enough)), pu(14, static_cast<unsigned>(cs_count)), pu(15, static_cast<unsigned>(cs_has_tone));
+        p64(16, cf_found), p64(18, cf_not_found), p64(20, cs_found), p64(22, cs_not_found);
+        p64(24, active);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0)
+        *(aux_vu32*)&x->done = 1u;
+}
+
+// One channel per workgroup of three waves: the channel itself (as k_demod<true>), the pre-filter wave ahead of it and, behind it,
+// the audio wave of an NFM channel.
+struct PwShare {
+    PreShare pre;
+    AuxShare aux;
+};
+__global__ __launch_bounds__(192) void k_demod_pw(const DemodArgs a) {
+    __shared__ PwShare sh_mem;
+    LdsPre* const pre = (LdsPre*)&sh_mem.pre;
+    LdsAux* const aux = (LdsAux*)&sh_mem.aux;
+    if (threadIdx.x == 0) {
         pre->h_done = 0, pre->m_pos = 0;
+        aux->d_head = 0, aux->d_tail = 0, aux->tk_tail = 0, aux->done = 0;
+    }
     __syncthreads();
+    if (threadIdx.x >= 128) {
+        audio_wave(a, aux, static_cast<int>(threadIdx.x) - 128);
+        return;
+    }
     if (threadIdx.x >= 64) {
         pre_wave(a, pre, static_cast<int>(threadIdx.x) - 64);
         return;
     }
-    demod_body<true, true>(a, pre);
+    demod_body<true, true>(a, pre, aux);
 }
 
 __global__ void k_init_state(ChanState* st, float* carry, float* sq_ring, float* ctcss_q, const ChanParams* cp, int nstreams, int nch,
@@ -1455,7 +1788,7 @@ hipError_t launch_demod(const DemodArgs& a, hipStream_t s) {
         return hipSuccess;
     const int blocks = (rows + a.lanes_per_wave - 1) / a.lanes_per_wave;
     if (a.lanes_per_wave == 1 && a.pre_wave && a.steady_blocks)
-        hipLaunchKernelGGL(k_demod_pw, dim3(blocks), dim3(128), 0, s, a);
+        hipLaunchKernelGGL(k_demod_pw, dim3(blocks), dim3(192), 0, s, a);
     else if (a.lanes_per_wave == 1)
         hipLaunchKernelGGL(k_demod<true>, dim3(blocks), dim3(64), 0, s, a);
     else

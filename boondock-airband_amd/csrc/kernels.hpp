@@ -104,6 +104,7 @@ struct DemodArgs {
     int lanes_per_wave;
     int steady_blocks;  // one channel per wave: take runs of steady CLOSED / OPEN steps 64 at a time (demod.hip)
     int pre_wave;       // ... with a second wave per channel that walks the pre-filter averages + noise floor ahead (k_demod_pw)
+    int audio_wave;     // ... and, for NFM channels, a third that takes everything behind the filtered I/Q: audio, CTCSS, gate, stores
     unsigned* pre_timeouts;  // (device counter) waits of a channel wave for its pre-filter wave that ran out: expected 0
 };
 

@@ -113,6 +113,7 @@ struct mi_demod {
     double opt_tp_ratio = 0;  // MI_OPT_TP_RATIO_PCT / 100: 0 = measured default
     int opt_tp_lpw = 0;       // MI_OPT_TP_SEG_LANES: lanes per wave of the segment pass, 0 = auto
     int opt_pre_wave = -1;       // MI_OPT_PRE_WAVE: serial kernel, one channel per wave: a second wave walks the squelch pre-filter ahead (k_demod_pw); -1 = up to 512 rows
+    bool opt_audio_wave = true;  // MI_OPT_AUDIO_WAVE: ... and NFM channels a third wave for everything behind the filtered I/Q (audio, CTCSS, gate, stores)
     bool opt_spec_head = true;   // MI_OPT_SPEC_HEAD: overlapped calls start their first segments from a guessed state (see TpArgs)
     int opt_tp_eager = 0;        // (diagnostic, MI_AIRBAND_TP_EAGER)
     int opt_core_lead = 0;       // (diagnostic, MI_AIRBAND_CORE_LEAD) blocks the noise-floor wave may run ahead, 0 = default
@@ -281,6 +282,8 @@ void tuning_from_env(mi_demod* h) {
         h->opt_core_guess = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_PRE_WAVE"))
         h->opt_pre_wave = std::atoi(e) < 0 ? -1 : (std::atoi(e) != 0 ? 1 : 0);
+    if (const char* e = get("MI_AIRBAND_AUDIO_WAVE"))
+        h->opt_audio_wave = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_SPEC_HEAD"))
         h->opt_spec_head = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_L64"))
@@ -429,6 +432,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     // +12 %); with a thousand rows and more the machine is full and a second wave per row only takes LDS and issue slots from
     // stage 1 (32 streams: +-0, 64 streams: -27 %)
     da.pre_wave = (h->opt_pre_wave < 0 ? h->rows <= 512 : h->opt_pre_wave != 0) ? 1 : 0;
+    da.audio_wave = h->opt_audio_wave ? 1 : 0;
     da.pre_timeouts = h->d_pre_timeouts;
 
     // the serial kernels expect the carried AGC_EXTRA samples of every row at the front of the planes they work on
@@ -1858,6 +1862,9 @@ int mi_demod_set_option(mi_demod* h, int option, int value) {
             return MI_OK;
         case MI_OPT_LANE_FFT_JIT:
             h->opt_l64_jit = value != 0;
+            return MI_OK;
+        case MI_OPT_AUDIO_WAVE:
+            h->opt_audio_wave = value != 0;
             return MI_OK;
         default:
             return fail(MI_ERR_INVALID, "unknown option");

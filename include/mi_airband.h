@@ -276,6 +276,9 @@ enum {
                                * up to 64 rows, 0 beyond; 0 never.  Takes effect only when the stream handed to mi_demod_process_device is not
                                * the NULL stream (the restricted streams are blocking ones: hipExtStreamCreateWithCUMask); set before the first
                                * time-parallel call.  The host-buffer entries use the handle's own stream and always qualify. */
+    MI_OPT_AUDIO_WAVE = 16,   /* 1 (default): where MI_OPT_PRE_WAVE applies, an NFM channel gets a third wave that takes everything behind the
+                               * filtered I/Q -- discriminator, DC block, de-emphasis, the CTCSS detector banks, output gate, notch filter,
+                               * axcindicate and the audio / raw-I/Q stores -- from the channel's own wave (demod.hip, audio_wave) */
     MI_OPT_LANE_FFT_JIT = 11  /* 1 (default): that kernel is compiled for the plan's own FFT nodes by hipRTC on first use (the code object is
                                * cached per (device, hop, masks) for the life of the process); 0, or hipRTC missing: the prebuilt full graph */
 };
