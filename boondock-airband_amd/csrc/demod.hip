@@ -24,6 +24,43 @@ enum : int { SQ_CLOSED = 0, SQ_OPENING = 1, SQ_CLOSING = 2, SQ_LOW_SIGNAL_ABORT 
 constexpr int kOpenDelay = 197, kCloseDelay = 197, kLowSignalAbort = 88;  // squelch.cpp:49-51
 constexpr uint32_t kRecentSampleSize = 1000, kFlapOpensThreshold = 3;    // squelch.cpp:62-63
 
+// ---- channel types ----
+// A lone wave pays 10 / 24 cycles for a scalar branch (not taken / taken) and 21 / 35 for an exec-masked region (entered / skipped) --
+// as much as 3 to 9 vector instructions (tools/micro/branch_cost.hip) -- and the per-channel loop is full of tests of the channel's
+// configuration.  With one channel per wave the configuration is the same for the whole kernel, so the loop is compiled once per
+// common type with those fields as constants (apply() overwrites the loaded ChanParams with what the dispatch has checked: every
+// test of them folds away) and once with everything open.  A negative parameter leaves its field as loaded.
+template <int kMod, int kRaw, int kIqo, int kLp, int kCtcss, int kNotch, int kManual>
+struct ChanType {
+    static __device__ __forceinline__ bool matches(const ChanParams& p) {
+        return (kMod < 0 || p.modulation == kMod) && (kRaw < 0 || (p.needs_raw_iq != 0) == (kRaw != 0)) &&
+               (kIqo < 0 || (p.has_iq_outputs != 0) == (kIqo != 0)) && (kLp < 0 || (p.lowpass_enabled != 0) == (kLp != 0)) &&
+               (kCtcss < 0 || (p.ctcss_enabled != 0) == (kCtcss != 0)) && (kNotch < 0 || (p.notch_enabled != 0) == (kNotch != 0)) &&
+               (kManual < 0 || (p.using_manual_level != 0) == (kManual != 0));
+    }
+    static __device__ __forceinline__ void apply(ChanParams& p) {
+        if (kMod >= 0)
+            p.modulation = kMod;
+        if (kRaw >= 0)
+            p.needs_raw_iq = kRaw;
+        if (kIqo >= 0)
+            p.has_iq_outputs = kIqo;
+        if (kLp >= 0)
+            p.lowpass_enabled = kLp;
+        if (kCtcss >= 0)
+            p.ctcss_enabled = kCtcss;
+        if (kNotch >= 0)
+            p.notch_enabled = kNotch;
+        if (kManual >= 0)
+            p.using_manual_level = kManual;
+    }
+    static constexpr int raw = kRaw;
+};
+using TyAny = ChanType<-1, -1, -1, -1, -1, -1, -1>;
+using TyAmPlain = ChanType<MI_MOD_AM, 0, 0, 0, 0, 0, 0>;      // what tp.hip also takes: AM, nothing else
+using TyNfmLp = ChanType<MI_MOD_NFM, 1, 0, 1, -1, -1, 0>;     // NFM with a low-pass filter (CTCSS / notch as configured)
+using TyNfm = ChanType<MI_MOD_NFM, 1, 0, 0, -1, -1, 0>;       // NFM without
+
 // ---- the audio wave's mailbox (k_demod_pw, NFM channels) ----
 // The channel wave (FSM, filter) posts, in the order of the steps: the filtered I/Q of every step whose audio is processed
 // (should_process_audio(): OPEN or CLOSING) as BLOCKs of 1..64 consecutive steps, the CTCSS resets (a transition to CLOSED),
@@ -445,6 +482,116 @@ __device__ __forceinline__ void ema_passes16(float& F, float& C, float& T, float
                  : "vcc");
 }
 
+// ... and of full_ alone: two instructions per step and the two wait states a DPP read of a fresh result needs
+#define MI_FULL_PASS                              \
+    "v_mul_f32_dpp %[T], %[F], %[K]" MI_EMA_DPP   \
+    "v_add_f32 %[F], %[T], %[B]\n"                \
+    "s_nop 1\n"
+#define MI_FULL_PASS4 MI_FULL_PASS MI_FULL_PASS MI_FULL_PASS MI_FULL_PASS
+__device__ __forceinline__ void full_passes16(float& F, float& T, const float B) {
+    const float K = 0.99f;
+    asm volatile("s_nop 1\n" MI_FULL_PASS4 MI_FULL_PASS4 MI_FULL_PASS4 MI_FULL_PASS4 : [F] "+v"(F), [T] "+v"(T) : [B] "v"(B), [K] "v"(K));
+}
+
+// One noise-floor period [L, E) (at most 16 steps; lane m = step m) of the pre-filter averages (squelch.cpp:501-514) under the period's
+// cap.  Fin / Cin: full_ / capped_ entering it (wave-uniform).  Two regimes need the recurrence of full_ only -- a third of the
+// instructions of the pair:
+//   MERGED     capped_ == full_ bit for bit on entry, below the cap, and full_ stays below it: the cap never binds and
+//              `capped_ >= cap` never holds, so capped_ takes full_'s values (the same operations on the same operands);
+//   SATURATED  every step leaves capped_ at the cap: either capped_ >= cap before it and the sample >= cap (squelch.cpp:509-510
+//              assigns the cap), or the average it forms from them is >= cap (std::min returns the cap).  The first step of a
+//              period usually goes the second way -- the cap has just risen with the noise floor.
+// Both are verified for the whole period before anything is taken; otherwise the pair is walked as before.  Every lane runs
+// every pass: lanes before L reproduce the values they have, whichever way they got them (all are the recurrence's values).
+__device__ __forceinline__ void pre_period(float& F, float& C, float& T, float& Pc, const float b, const float x, const float cap, const float CAPv,
+                                           float& CAPX, const int L, const int E, const int lane, const float Fin, const float Cin) {
+    const bool mine = lane >= L;
+    const bool in_period = mine && lane < E;
+    CAPX = mine ? (x >= cap ? cap : __builtin_inff()) : CAPX;  // cap where sample >= cap, else +inf
+    if (__float_as_uint(Cin) == __float_as_uint(Fin) && Cin < cap) {
+        full_passes16(F, T, b);
+        if (__ballot(in_period && !(F < cap)) == 0ull) {
+            C = in_period ? F : C;
+            return;
+        }
+    } else {
+        const float Cp = lane == L ? Cin : cap;  // capped_ before the step, if every step before it left the cap
+        const bool at_cap = (x >= cap && Cp >= cap) || (Cp * 0.99f + b >= cap);
+        if (__ballot(in_period && !at_cap) == 0ull) {
+            full_passes16(F, T, b);
+            C = in_period ? cap : C;
+            return;
+        }
+    }
+    ema_passes16(F, C, T, Pc, b, CAPv, CAPX);  // a period is at most 16 steps; further passes change nothing
+}
+
+// The pre-filter averages and the noise floor (squelch.cpp:201-214, 477-514) over the steps [0, kmax) of a block, lane m = step m.
+// In: the state entering the block (nf, cap, full, capd, sample_count_ sc) and the lane's sample x.  Out, per lane: full_ (F),
+// capped_ (C), noise_floor_ (NFv) and moving_avg_cap_ (CAPv) after its step; nf / cap leave as they are after the block;
+// zero_from = the first step that updates the noise floor (64: none).
+// A period costs a lone wave more in bookkeeping than in arithmetic (~500 of ~800 cycles), so the two regimes of pre_period() are
+// first tried for the block as a whole: full_ alone over all its steps, then the (at most five) noise-floor updates from the
+// values capped_ would have at the period ends -- full_'s (MERGED) or the previous period's cap (SATURATED) -- and one check of
+// every step's precondition under its own period's cap.  If it holds the values are the recurrence's; if not, nothing has been
+// taken and the periods are walked one by one.
+__device__ __forceinline__ void pre_block(const ChanParams& P, float& nf, float& cap, const float full, const float capd, const uint32_t sc, const float x,
+                                          const int kmax, const int lane, float& F, float& C, float& NFv, float& CAPv, int& zero_from) {
+    const float k99 = 0.99f, n99 = static_cast<float>(1.0 - static_cast<double>(0.99f));
+    const float k97 = 0.97f, n97 = static_cast<float>(1.0 - static_cast<double>(0.97f));
+    const float b = x * n99;
+    const int nb0 = __builtin_amdgcn_readfirstlane((15 - static_cast<int>(sc & 15u)) & 15);  // first step whose sample_count_ is a multiple of 16
+    zero_from = nb0 < kmax ? nb0 : 64;
+    const bool merged = __float_as_uint(capd) == __float_as_uint(full);
+    if (merged || capd >= cap * 0.96875f) {  // (SATURATED: the cap has risen a little with the noise floor since capped_ was set to it)
+        float Ft = 0.0f, T = full * k99;  // T: what lane 0 keeps reading (its shifted source does not exist)
+        for (int p_ = 0; p_ < kmax; p_ += 16)
+            full_passes16(Ft, T, b);
+        float nf2 = nf, cap2 = cap, NF2 = nf, CAP2 = cap;
+        for (int nb = nb0; nb < kmax; nb += 16) {  // calculate_noise_floor with capped_ as step nb-1 left it, squelch.cpp:477-490
+            const float Cb = nb == 0 ? capd : (merged ? lane_read(Ft, nb - 1) : cap2);
+            nf2 = nf2 * k97 + std_min(Cb, nf2) * n97 + 1e-6f;
+            cap2 = P.using_manual_level ? P.manual_cap : P.cap_factor * nf2;
+            const bool mine = lane >= nb;
+            NF2 = mine ? nf2 : NF2;
+            CAP2 = mine ? cap2 : CAP2;
+        }
+        bool bad;
+        if (merged) {  // capped_ before and after the step stays below the step's cap: the cap never binds, capped_ >= cap never holds
+            const float Fp = shr1(Ft, full);
+            bad = !(Ft < CAP2 && Fp < CAP2);
+        } else {  // the step leaves the cap: squelch.cpp:509-510 assigns it, or the average formed from capped_ and the sample reaches it
+            const float Cp = shr1(CAP2, capd);
+            bad = !((x >= CAP2 && Cp >= CAP2) || (Cp * k99 + b >= CAP2));
+        }
+        if (__ballot(bad && lane < kmax) == 0ull) {
+            F = Ft, C = merged ? Ft : CAP2, NFv = NF2, CAPv = CAP2;
+            nf = nf2, cap = cap2;
+            return;
+        }
+    }
+    // Every lane runs every pass with its own cap: the lanes before the current period have their final values and reproduce
+    // them, the first lane of the period finds its predecessor's final value one lane down.
+    F = 0.0f, C = 0.0f, NFv = nf, CAPv = cap;
+    float T = full * k99, Pc = capd;  // what lane 0 keeps reading
+    float CAPX = __builtin_inff();
+    int L = 0, nb = nb0;
+    while (L < kmax) {
+        const float Fin = L ? lane_read(F, L - 1) : full, Cin = L ? lane_read(C, L - 1) : capd;
+        if (L == nb) {  // calculate_noise_floor with the averages step L-1 left, squelch.cpp:477-490
+            nf = nf * k97 + std_min(Cin, nf) * n97 + 1e-6f;
+            cap = P.using_manual_level ? P.manual_cap : P.cap_factor * nf;
+            nb += 16;
+        }
+        const int E = min(nb, kmax);
+        const bool mine = lane >= L;
+        NFv = mine ? nf : NFv;
+        CAPv = mine ? cap : CAPv;
+        pre_period(F, C, T, Pc, b, x, cap, CAPv, CAPX, L, E, lane, Fin, Cin);
+        L = E;
+    }
+}
+
 #ifdef MI_BLOCK_PROF
 #define MI_PROF_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); io.prof[k] += t_ - io.prof_t; io.prof_t = t_; } while (0)
 #else
@@ -535,6 +682,7 @@ struct BlockIo {
     float* wmain;
     float* carry;
     float2* iqo;
+    bool has_z, has_iqo;  // zrow / iqo are there (from the channel's type: constants in the typed instantiations)
     uint32_t n;
     // wavein of the 64 steps after the previous block, requested while that block ran (its first use is the block's first
     // operation; everything else a block loads is needed late enough to hide behind the pre-filter chain)
@@ -551,7 +699,8 @@ struct BlockIo {
 //   OPEN              + has_signal() must hold; audio
 //   CLOSING           as OPEN without the has_signal() test (it is only asked when the delay runs out)
 //   LOW_SIGNAL_ABORT  averages + noise floor only
-template <bool kPre>
+// kSt: the state the block is in where the caller has branched on it (CLOSED, OPEN), else -1
+template <bool kPre, int kSt>
 __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo& io, const uint32_t i0_, const int kmax_, bool& batch_open, LdsPre* pre, bool& pre_on) {
     // wave-uniform by construction; say so, so that loop control stays on the scalar unit
     const uint32_t i0 = __builtin_amdgcn_readfirstlane(i0_);
@@ -559,16 +708,15 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     ChanState& s = c.s;
     const ChanParams& P = c.p;
     const int lane = c.lane;
-    const int st = s.current_state;
+    const int st = kSt >= 0 ? kSt : s.current_state;
     const bool m_closed = st == SQ_CLOSED, m_open = st == SQ_OPEN, m_opening = st == SQ_OPENING, m_abort = st == SQ_LOW_SIGNAL_ABORT;
     const bool do_lsc = !m_closed && !m_abort;           // the low-signal count runs (squelch.cpp:233-245)
-    const bool do_filter = do_lsc && io.zrow != nullptr;  // should_filter_sample() holds on every step
-    const bool lp = P.lowpass_enabled && io.zrow;
+    const bool do_filter = do_lsc && io.has_z;  // should_filter_sample() holds on every step
+    const bool lp = P.lowpass_enabled && io.has_z;
     const bool do_post = lp && do_lsc && (!m_opening || s.delay + 1 >= kSquelchRing);  // process_filtered_sample gets past its early return
     const bool post_init = do_post && m_opening && s.delay + 1 == kSquelchRing;         // ... and starts from buffer_[buffer_tail_]
     const bool do_audio = m_open || st == SQ_CLOSING;     // should_process_audio()
     const float k99 = 0.99f, n99 = static_cast<float>(1.0 - static_cast<double>(0.99f));
-    const float k97 = 0.97f, n97 = static_cast<float>(1.0 - static_cast<double>(0.97f));
     const unsigned long long actmask = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
 
 #ifdef MI_BLOCK_PROF
@@ -589,7 +737,6 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
         x = io.magrow[kAgcExtra + min(i0 + static_cast<uint32_t>(lane), io.n - 1u)];
         asm volatile("" : "+v"(x));  // the wait for this load stays inside the branch
     }
-    const float b = x * n99;
     __builtin_amdgcn_sched_barrier(0);
     {
         const uint32_t ni = i0 + static_cast<uint32_t>(kmax);
@@ -600,7 +747,7 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     const uint32_t li = min(i0 + static_cast<uint32_t>(lane), io.n - 1u);  // lanes past kmax read a valid address, nobody uses the value
     const float ax = io.magrow[li];  // wavein[j - AGC_EXTRA]
     // (an unconditional load: a value that is merged with a constant at a join is waited for at the join)
-    const float2 z = (io.zrow ? io.zrow : reinterpret_cast<const float2*>(io.magrow))[io.zrow ? li : (li >> 1)];
+    const float2 z = (io.has_z ? io.zrow : reinterpret_cast<const float2*>(io.magrow))[io.has_z ? li : (li >> 1)];
     float rt = 0.0f;  // buffer_[buffer_tail_] as step m sees it
     if (do_post) {
         int t = s.buffer_tail + 1 + lane;
@@ -634,28 +781,9 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
         }
     }
     if (!from_ring) {
-        // Every lane runs every pass with its own cap: the lanes before the current sixteen-step stretch have their final
-        // values and reproduce them, the first lane of the stretch finds its predecessor's final value one lane down.
-        float T = s.pre_full * k99, Pc = s.pre_capped;  // what lane 0 keeps reading (its shifted source does not exist)
-        float CAPX = __builtin_inff();                  // cap where sample >= cap, else +inf
-        int L = 0;
-        int nb = __builtin_amdgcn_readfirstlane((15 - static_cast<int>(s.sample_count & 15u)) & 15);  // first step whose sample_count_ is a multiple of 16
-        while (L < kmax) {
-            if (L == nb) {  // calculate_noise_floor with the averages step L-1 left, squelch.cpp:477-490
-                const float Cin = L ? lane_read(C, L - 1) : s.pre_capped;
-                nf = nf * k97 + std_min(Cin, nf) * n97 + 1e-6f;
-                cap = P.using_manual_level ? P.manual_cap : P.cap_factor * nf;
-                zero_from = min(zero_from, L);
-                nb += 16;
-            }
-            const int E = min(nb, kmax);
-            const bool mine = lane >= L;
-            NFv = mine ? nf : NFv;
-            CAPv = mine ? cap : CAPv;
-            CAPX = mine ? (x >= cap ? cap : __builtin_inff()) : CAPX;
-            ema_passes16(F, C, T, Pc, b, CAPv, CAPX);  // a stretch is at most 16 steps; further passes change nothing
-            L = E;
-        }
+        int zf = 64;
+        pre_block(P, nf, cap, s.pre_full, s.pre_capped, s.sample_count, x, kmax, lane, F, C, NFv, CAPv, zf);
+        zero_from = min(zero_from, zf);
     }
     MI_PROF_MARK(0);
     // squelch_level() as step m evaluates it (cache and all, squelch.cpp:164-177)
@@ -677,7 +805,7 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     }
     // Does a step evaluate squelch_level() at all?  Everywhere except in LOW_SIGNAL_ABORT on a channel without raw I/Q, where
     // the sample loop never asks should_filter_sample(): there the cache stays cleared after a noise-floor update.
-    const bool level_used = !(m_abort && io.zrow == nullptr);
+    const bool level_used = !(m_abort && !io.has_z);
     const bool has_pre = C >= level;
 
     bool fail = m_closed ? has_pre : (m_open ? !has_pre : false);
@@ -847,7 +975,7 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
             const uint32_t v = kAgcExtra + i0 + lane;
             float* dst = (v < io.n) ? io.wmain + v : io.carry + (v - io.n);
             *dst = out;
-            if (io.iqo)
+            if (io.has_iqo)
                 io.iqo[i0 + lane] = gate ? make_float2(re, im) : make_float2(0.0f, 0.0f);
         }
     }
@@ -923,10 +1051,95 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     return kc;
 }
 
+// the end of a WAVE_BATCH: axcindicate and active_counter (rtl_airband.cpp:523,628,667-669) -- the audio wave's where it judges is_open()
+#define MI_END_BATCH()                                                                                                 \
+    do {                                                                                                               \
+        if (c.split) {                                                                                                 \
+            aux_post(c, AUX_BATCH, 0u, batch, 0.0f, 0.0f);                                                             \
+        } else {                                                                                                       \
+            a.axc[static_cast<size_t>(row) * a.axc_stride + batch] = batch_open ? MI_SIGNAL : MI_NO_SIGNAL;           \
+            if (batch_open)                                                                                            \
+                c.s.active_counter++;                                                                                  \
+        }                                                                                                              \
+        batch_open = false;                                                                                            \
+        in_batch = 0;                                                                                                  \
+        batch++;                                                                                                       \
+    } while (0)
+
+
+// A run of steady blocks in one state (current_state_ == next_state_ == kSt, or whatever it is for kSt < 0): a block never changes
+// the state, so while blocks commit in full nothing but their lengths has to be worked out between them -- the batch end, the
+// 16-step phase of sample_count_, and in the waiting states the step whose delay_ decides.  Returns with gi at the first group no
+// block took (possibly ngroups); `skip` says how many groups the sample loop should take before blocks are tried again.
+template <bool kPre, int kSt>
+__device__ __forceinline__ void steady_streak(Ctx& c, const DemodArgs& a, BlockIo& bio, uint32_t& gi, const uint32_t ngroups, uint32_t& in_batch,
+                                              uint32_t& batch, bool& batch_open, int& skip, bool& stale, LdsPre* pre, bool& pre_on, const int row) {
+    const ChanParams& P = c.p;
+    const int st = kSt >= 0 ? kSt : __builtin_amdgcn_readfirstlane(c.s.current_state);
+    const bool lpz = P.lowpass_enabled && bio.has_z;
+    for (;;) {
+        int kmax = min(64, static_cast<int>(ngroups - gi) * 4);
+        kmax = min(kmax, kWaveBatch - static_cast<int>(in_batch));  // the batch flag is written at a batch's last step
+        // end on a multiple of 16 of sample_count_: the blocks after this one then see whole noise-floor periods
+        const int phase = static_cast<int>((__builtin_amdgcn_readfirstlane(c.s.sample_count) + 1u) & 15u);
+        if (phase && kmax == 64)
+            kmax = 64 - phase;
+        bool ok = true;
+        if (st == SQ_OPENING || st == SQ_CLOSING || st == SQ_LOW_SIGNAL_ABORT) {
+            const int delay = __builtin_amdgcn_readfirstlane(c.s.delay);
+            // the step whose delay_ reaches open_delay_ / close_delay_ decides: the sample loop takes it
+            kmax = min(kmax, (st == SQ_OPENING ? kOpenDelay : kCloseDelay) - 1 - delay);
+            if (st == SQ_OPENING && lpz) {
+                const int upf = __builtin_amdgcn_readfirstlane(c.s.using_post_filter);
+                if (delay + 1 < kSquelchRing) {  // process_filtered_sample still returns early ...
+                    kmax = min(kmax, kSquelchRing - 1 - delay);
+                    ok = upf == 0;
+                } else {  // ... or runs on every step (it starts from buffer_[buffer_tail_] at delay_ == buffer_size_)
+                    ok = upf == (delay + 1 == kSquelchRing ? 0 : 1);
+                }
+            }
+        }
+        if (st == SQ_OPEN || st == SQ_CLOSING) {
+            ok = ok && __builtin_amdgcn_readfirstlane(c.s.using_post_filter) == (lpz ? 1 : 0);
+            if (P.ctcss_enabled && !c.split) {  // a detector window's last sample is taken by the sample loop
+                kmax = min(kmax, P.ctcss_slow_window - 1 - __builtin_amdgcn_readfirstlane(c.s.cs_count));
+                if (!c.s.cs_enough)
+                    kmax = min(kmax, P.ctcss_fast_window - 1 - __builtin_amdgcn_readfirstlane(c.s.cf_count));
+            }
+        }
+        if (!ok)
+            kmax = 0;
+        kmax &= ~3;
+        if (kmax < 8)
+            return;  // the sample loop takes this group
+        const int kc = steady_block<kPre, kSt>(c, a, bio, gi * 4, kmax, batch_open, pre, pre_on);
+        if (kc > 0) {
+            in_batch += static_cast<uint32_t>(kc);
+            if (in_batch == kWaveBatch)
+                MI_END_BATCH();
+            gi += static_cast<uint32_t>(kc / 4);
+            stale = true;  // the group fetched ahead is behind us now
+        }
+#ifdef MI_BLOCK_PROF
+        {   // split "between blocks": bookkeeping after the return vs loop head + eligibility
+            const unsigned long long t_ = __builtin_readcyclecounter();
+            bio.after_ret += t_ - bio.prof_t;
+            bio.prof_t = t_;
+        }
+#endif
+        if (kc != kmax) {  // a step of the block wants something else: it is among the next four
+            skip = 4;
+            return;
+        }
+        if (gi >= ngroups)
+            return;
+    }
+}
+
 // kUni: one channel per wave -- all 64 lanes run it in lockstep on the same values.  It is its own instantiation so that
 // the compiler's uniformity analysis sees a row that depends on blockIdx alone: the channel state then sits in scalar
 // registers where it can, the state machine's integer work runs on the scalar unit and its branches are scalar branches.
-template <bool kUni, bool kPre>
+template <bool kUni, bool kPre, class T>
 __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsAux* aux) {
     bool pre_on = kPre;  // the pre-filter wave is there and delivering (k_demod_pw)
     const int rows = a.nstreams * a.nch;
@@ -941,6 +1154,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
     c.gf_c = c.gf_q1 = c.gf_q2 = c.gs_c = c.gs_q1 = c.gs_q2 = 0.0f;
     c.s = a.st[row];
     c.p = a.cp[ch];
+    T::apply(c.p);
     const ChanParams& P = c.p;
     c.split = kPre && a.audio_wave && P.modulation != MI_MOD_AM;  // (the audio wave decides the same way)
     c.aux = aux;
@@ -967,6 +1181,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
     float* __restrict__ wmain = a.wmain + static_cast<size_t>(row) * a.wmain_stride;
     float* __restrict__ carry = a.carry + static_cast<size_t>(row) * kAgcExtra;
     float2* __restrict__ iqo = (a.iq_out && P.has_iq_outputs) ? a.iq_out + static_cast<size_t>(row) * a.iq_out_stride : nullptr;
+    const bool has_z = P.needs_raw_iq != 0, has_iqo = iqo != nullptr;
     const uint32_t n = a.nsteps;
     // virtual waveout: index v in [0, n) is emitted audio, [n, n+AGC_EXTRA) is the lookahead kept in `carry`
     auto W = [&](uint32_t v) -> float& { return v < n ? wmain[v] : carry[v - n]; };
@@ -979,21 +1194,6 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
     const float ampfactor = P.ampfactor;
     bool batch_open = false;
     uint32_t in_batch = 0, batch = 0;
-    // the end of a WAVE_BATCH: axcindicate and active_counter (rtl_airband.cpp:523,628,667-669) -- the audio wave's where it judges is_open()
-#define MI_END_BATCH()                                                                                                 \
-    do {                                                                                                               \
-        if (c.split) {                                                                                                 \
-            aux_post(c, AUX_BATCH, 0u, batch, 0.0f, 0.0f);                                                             \
-        } else {                                                                                                       \
-            a.axc[static_cast<size_t>(row) * a.axc_stride + batch] = batch_open ? MI_SIGNAL : MI_NO_SIGNAL;           \
-            if (batch_open)                                                                                            \
-                c.s.active_counter++;                                                                                  \
-        }                                                                                                              \
-        batch_open = false;                                                                                            \
-        in_batch = 0;                                                                                                  \
-        batch++;                                                                                                       \
-    } while (0)
-
     // Memory traffic is batched four steps at a time: the inputs of steps i0+4 .. i0+7 are requested (16 B per row and
     // plane) while steps i0 .. i0+3 run, and the four outputs leave as one 16-B store.  A load's wait also waits for every
     // older store of the wave (vmcnt is in issue order), so a store per step would put the write latency on every step.
@@ -1004,14 +1204,14 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
     const uint32_t ngroups = n / 4;
     float4 nx = xg[0], na = ag[0];
     float4 nz0 = make_float4(0.f, 0.f, 0.f, 0.f), nz1 = nz0;
-    if (zrow)
+    if (has_z)
         nz0 = zg[0], nz1 = zg[1];
 
 #ifdef MI_BLOCK_PROF
-    BlockIo bio{{0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0, magrow, zrow, wmain, carry, iqo, n, 0.0f, 0xffffffffu};
+    BlockIo bio{{0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0, magrow, zrow, wmain, carry, iqo, has_z, has_iqo, n, 0.0f, 0xffffffffu};
     const unsigned long long prof_k0 = __builtin_readcyclecounter();
 #else
-    BlockIo bio{magrow, zrow, wmain, carry, iqo, n, 0.0f, 0xffffffffu};
+    BlockIo bio{magrow, zrow, wmain, carry, iqo, has_z, has_iqo, n, 0.0f, 0xffffffffu};
 #endif
     int skip = 0;  // groups to take one by one before the next steady block is tried
     // After a block the group fetched ahead is not the next one.  It is fetched again only if the sample loop really takes
@@ -1021,66 +1221,21 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
     {
         for (uint32_t gi = 0; gi < ngroups; ++gi) {
           if constexpr (kUni) {
-              // wave-uniform by construction (one channel per wave): say so, so that this stays on the scalar unit
-              const int st = __builtin_amdgcn_readfirstlane(c.s.current_state);
-              const int nxt = __builtin_amdgcn_readfirstlane(c.s.next_state);
-              const bool lpz = P.lowpass_enabled && zrow;
               if (skip > 0) {
                   --skip;
-              } else if (a.steady_blocks && st == nxt) {
-                  const int delay = __builtin_amdgcn_readfirstlane(c.s.delay);
-                  const int upf = __builtin_amdgcn_readfirstlane(c.s.using_post_filter);
-                  int kmax = min(64, static_cast<int>(ngroups - gi) * 4);
-                  kmax = min(kmax, kWaveBatch - static_cast<int>(in_batch));  // the batch flag is written at a batch's last step
-                  // end on a multiple of 16 of sample_count_: the blocks after this one then see whole noise-floor periods
-                  const int phase = static_cast<int>((__builtin_amdgcn_readfirstlane(c.s.sample_count) + 1u) & 15u);
-                  if (phase && kmax == 64)
-                      kmax = 64 - phase;
-                  bool ok = true;
-                  if (st == SQ_OPENING || st == SQ_CLOSING || st == SQ_LOW_SIGNAL_ABORT) {
-                      // the step whose delay_ reaches open_delay_ / close_delay_ decides: the sample loop takes it
-                      kmax = min(kmax, (st == SQ_OPENING ? kOpenDelay : kCloseDelay) - 1 - delay);
-                      if (st == SQ_OPENING && lpz) {
-                          if (delay + 1 < kSquelchRing) {  // process_filtered_sample still returns early ...
-                              kmax = min(kmax, kSquelchRing - 1 - delay);
-                              ok = upf == 0;
-                          } else {  // ... or runs on every step (it starts from buffer_[buffer_tail_] at delay_ == buffer_size_)
-                              ok = upf == (delay + 1 == kSquelchRing ? 0 : 1);
-                          }
-                      }
-                  }
-                  if (st == SQ_OPEN || st == SQ_CLOSING) {
-                      ok = ok && upf == (lpz ? 1 : 0);
-                      if (P.ctcss_enabled && !c.split) {  // a detector window's last sample is taken by the sample loop
-                          kmax = min(kmax, P.ctcss_slow_window - 1 - __builtin_amdgcn_readfirstlane(c.s.cs_count));
-                          if (!c.s.cs_enough)
-                              kmax = min(kmax, P.ctcss_fast_window - 1 - __builtin_amdgcn_readfirstlane(c.s.cf_count));
-                      }
-                  }
-                  if (!ok)
-                      kmax = 0;
-                  kmax &= ~3;
-                  if (kmax >= 8) {
-                      const int kc = steady_block<kPre>(c, a, bio, gi * 4, kmax, batch_open, pre, pre_on);
-                      if (kc > 0) {
-                          in_batch += static_cast<uint32_t>(kc);
-                          if (in_batch == kWaveBatch)
-                              MI_END_BATCH();
-                          gi += static_cast<uint32_t>(kc / 4);
-                          stale = true;  // the group fetched ahead is behind us now
-                          if (kc < 8)
-                              skip = 8;
-#ifdef MI_BLOCK_PROF
-                          {   // (experiment) split "between blocks": bookkeeping after the return vs loop head + eligibility
-                              const unsigned long long t_ = __builtin_readcyclecounter();
-                              bio.after_ret += t_ - bio.prof_t;
-                              bio.prof_t = t_;
-                          }
-#endif
-                          --gi;  // the loop increment
-                          continue;
-                      }
-                      skip = 4;
+              } else if (a.steady_blocks) {
+                  // wave-uniform by construction (one channel per wave): say so, so that this stays on the scalar unit
+                  const int st = __builtin_amdgcn_readfirstlane(c.s.current_state);
+                  const int nxt = __builtin_amdgcn_readfirstlane(c.s.next_state);
+                  if (st == nxt) {  // (a branch on the state here, and the blocks' own tests of it fold away)
+                      if (st == SQ_CLOSED)
+                          steady_streak<kPre, SQ_CLOSED>(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
+                      else if (st == SQ_OPEN)
+                          steady_streak<kPre, SQ_OPEN>(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
+                      else
+                          steady_streak<kPre, -1>(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
+                      if (gi >= ngroups)
+                          break;
                   }
               }
           }
@@ -1090,7 +1245,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
                   // A low-pass channel rewrites wavein[] with the filtered magnitude (rtl_airband.cpp:548): it must not pass the
                   // pre-filter wave, which reads the raw one.  Other channels only say where they are (the pre-filter wave stays
                   // within the ring's reach of that).
-                  if (P.lowpass_enabled && zrow) {
+                  if (P.lowpass_enabled && has_z) {
                       if (!pre_wait(pre, c.lane, i0, i0 + 4u)) {
                           pre_on = false;  // (it never came: this wave computes everything itself from here on)
                           if (c.lane == 0 && a.pre_timeouts)
@@ -1104,7 +1259,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
           if (stale) {
               nx = xg[gi];
               na = ag[gi];
-              if (zrow)
+              if (has_z)
                   nz0 = zg[2 * gi], nz1 = zg[2 * gi + 1];
               stale = false;
           }
@@ -1113,7 +1268,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
               const uint32_t gn = (gi + 1 < ngroups) ? gi + 1 : gi;
               nx = xg[gn];
               na = ag[gn];
-              if (zrow)
+              if (has_z)
                   nz0 = zg[2 * gn], nz1 = zg[2 * gn + 1];
           }
           const float gx[4] = {cx.x, cx.y, cx.z, cx.w}, ga[4] = {ca.x, ca.y, ca.z, ca.w};
@@ -1174,7 +1329,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
                       for (int m = 0; m < 4; ++m)
                           c.ring[ringi[m]] = ringv[m];
                   }
-                  if (iqo) {
+                  if (has_iqo) {
                       float4* z = reinterpret_cast<float4*>(iqo + i0);
                       z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
                       z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1194,7 +1349,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
 
             process_raw(c, x);  // rtl_airband.cpp:529
 
-            if (zrow && should_filter(c)) {  // rtl_airband.cpp:532-552
+            if (has_z && should_filter(c)) {  // rtl_airband.cpp:532-552
                 const uint32_t idx = c.s.dm_phi >> 16;  // sincosf_lut, util.cpp:113-127
                 const float fract = static_cast<float>(c.s.dm_phi & 0xffff) / 65536.0f;
                 float v1 = a.sin_lut[idx], v2 = a.sin_lut[idx + 1];
@@ -1302,11 +1457,11 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
                 else if (wout < -1.0f)
                     wout = -1.0f;
                 batch_open = true;
-                if (iqo)
+                if (has_iqo)
                     iqo[i] = make_float2(re, im);
             } else {
                 wout = 0.0f;
-                if (iqo && !((posted >> m) & 1u))
+                if (has_iqo && !((posted >> m) & 1u))
                     iqo[i] = make_float2(0.0f, 0.0f);
             }
             pend[m] = wout;
@@ -1340,7 +1495,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
         for (int v = 0; v < kAgcExtra; ++v)
             hrow[v] = magrow[n + v];
     }
-    if (zrow) {
+    if (has_z) {
         const size_t zoff = (static_cast<size_t>(stream) * a.n_iq_rows + P.iq_row) * a.plane_stride;
         const float2* zw = a.cplx + zoff;
         float2* zh = a.cplx_head + zoff;
@@ -1404,9 +1559,42 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
     }
 }
 
+// the channel's type picks the instantiation (one channel per wave; packed lanes take the open one)
+template <bool kUni, bool kPre>
+__device__ __forceinline__ void demod_dispatch(const DemodArgs& a, LdsPre* pre, LdsAux* aux) {
+    if constexpr (kUni) {
+        const ChanParams& P0 = a.cp[static_cast<int>(blockIdx.x) % a.nch];
+        if (TyAmPlain::matches(P0))
+            demod_body<kUni, kPre, TyAmPlain>(a, pre, aux);
+        else if (TyNfmLp::matches(P0))
+            demod_body<kUni, kPre, TyNfmLp>(a, pre, aux);
+        else if (TyNfm::matches(P0))
+            demod_body<kUni, kPre, TyNfm>(a, pre, aux);
+        else
+            demod_body<kUni, kPre, TyAny>(a, pre, aux);
+    } else {
+        demod_body<kUni, kPre, TyAny>(a, pre, aux);
+    }
+}
 template <bool kUni>
-__global__ __launch_bounds__(64) void k_demod(const DemodArgs a) {
-    demod_body<kUni, false>(a, nullptr, nullptr);
+#ifndef MI_UNI_EU
+#define MI_UNI_EU 3
+#endif
+#ifndef MI_PW_EU
+#define MI_PW_EU 2
+#endif
+#if MI_UNI_EU > 0
+#define MI_UNI_BOUNDS __launch_bounds__(64, MI_UNI_EU)
+#else
+#define MI_UNI_BOUNDS __launch_bounds__(64)
+#endif
+#if MI_PW_EU > 0
+#define MI_PW_BOUNDS __launch_bounds__(192, MI_PW_EU)
+#else
+#define MI_PW_BOUNDS __launch_bounds__(192)
+#endif
+__global__ MI_UNI_BOUNDS void k_demod(const DemodArgs a) {
+    demod_dispatch<kUni, false>(a, nullptr, nullptr);
 }
 
 // The pre-filter wave of k_demod_pw: the recurrence of steady_block()'s first phase, block after block over the whole call.
@@ -1416,13 +1604,14 @@ __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const 
     const ChanState& s0 = a.st[row];
     const float* __restrict__ xrow = a.mag + static_cast<size_t>(row) * a.plane_stride + kAgcExtra;
     const uint32_t n = a.nsteps;
-    const float k99 = 0.99f, n99 = static_cast<float>(1.0 - static_cast<double>(0.99f));
-    const float k97 = 0.97f, n97 = static_cast<float>(1.0 - static_cast<double>(0.97f));
     // the state the call starts from (wave-uniform)
     float nf = s0.noise_floor, cap = s0.moving_avg_cap, full = s0.pre_full, capd = s0.pre_capped;
     uint32_t sc = s0.sample_count;
     float xn = xrow[min(static_cast<uint32_t>(lane), n - 1u)];  // the next block's samples, requested a block ahead
     unsigned idle = 0;
+#ifdef MI_BLOCK_PROF
+    unsigned long long pw_t0 = __builtin_readcyclecounter(), pw_wait = 0, pw_load = 0, pw_per = 0, pw_tail = 0, pw_fast = 0, pw_n = 0;
+#endif
     for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
         const int kmax = static_cast<int>(min(64u, n - i0));
         // stay within the ring's reach of the channel wave (it posts its position before it waits for this wave)
@@ -1433,29 +1622,24 @@ __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const 
             }
         }
         idle = 0;
-        const float x = xn;
+#ifdef MI_BLOCK_PROF
+        unsigned long long pw_a = __builtin_readcyclecounter();
+        pw_wait += pw_a - pw_t0;
+#endif
+        float x = xn;
+        asm volatile("" : "+v"(x));
+#ifdef MI_BLOCK_PROF
+        unsigned long long pw_b = __builtin_readcyclecounter();
+        pw_load += pw_b - pw_a;
+#endif
         xn = xrow[min(i0 + 64u + static_cast<uint32_t>(lane), n - 1u)];
-        const float b = x * n99;
-        float F = 0.0f, C = 0.0f, NFv = nf, CAPv = cap;
-        float T = full * k99, Pc = capd;  // what lane 0 keeps reading (its shifted source does not exist)
-        float CAPX = __builtin_inff();
-        int L = 0;
-        int nb = __builtin_amdgcn_readfirstlane((15 - static_cast<int>(sc & 15u)) & 15);  // first step whose sample_count_ is a multiple of 16
-        while (L < kmax) {
-            if (L == nb) {  // calculate_noise_floor with the averages step L-1 left, squelch.cpp:477-490
-                const float Cin = L ? lane_read(C, L - 1) : capd;
-                nf = nf * k97 + std_min(Cin, nf) * n97 + 1e-6f;
-                cap = P.using_manual_level ? P.manual_cap : P.cap_factor * nf;
-                nb += 16;
-            }
-            const int E = min(nb, kmax);
-            const bool mine = lane >= L;
-            NFv = mine ? nf : NFv;
-            CAPv = mine ? cap : CAPv;
-            CAPX = mine ? (x >= cap ? cap : __builtin_inff()) : CAPX;
-            ema_passes16(F, C, T, Pc, b, CAPv, CAPX);
-            L = E;
-        }
+        float F, C, NFv, CAPv;
+        int zf;
+        pre_block(P, nf, cap, full, capd, sc, x, kmax, lane, F, C, NFv, CAPv, zf);
+#ifdef MI_BLOCK_PROF
+        unsigned long long pw_c = __builtin_readcyclecounter();
+        pw_per += pw_c - pw_b;
+#endif
         if (lane < kmax) {
             const unsigned at = (i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u);
             *(pre_vf32*)&pre->C[at] = C, *(pre_vf32*)&pre->F[at] = F, *(pre_vf32*)&pre->NF[at] = NFv, *(pre_vf32*)&pre->CAP[at] = CAPv;
@@ -1470,7 +1654,17 @@ __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const 
         full = lane_read(F, kmax - 1);
         capd = lane_read(C, kmax - 1);
         sc += static_cast<uint32_t>(kmax);
+#ifdef MI_BLOCK_PROF
+        pw_t0 = __builtin_readcyclecounter();
+        pw_tail += pw_t0 - pw_c;
+        ++pw_n;
+#endif
     }
+#ifdef MI_BLOCK_PROF
+    if (lane == 0 && (row == 0 || row == 5))
+        printf("preprof row %d: %llu blocks; per block: throttle %llu, sample wait %llu, periods %llu, ring + state %llu\n", row, pw_n, pw_wait / pw_n, pw_load / pw_n,
+               pw_per / pw_n, pw_tail / pw_n);
+#endif
 }
 
 // The audio wave of k_demod_pw (NFM channels): rtl_airband.cpp:587-641 and Squelch::process_audio_sample for the steps the channel
@@ -1699,7 +1893,7 @@ struct PwShare {
     PreShare pre;
     AuxShare aux;
 };
-__global__ __launch_bounds__(192) void k_demod_pw(const DemodArgs a) {
+__global__ MI_PW_BOUNDS void k_demod_pw(const DemodArgs a) {
     __shared__ PwShare sh_mem;
     LdsPre* const pre = (LdsPre*)&sh_mem.pre;
     LdsAux* const aux = (LdsAux*)&sh_mem.aux;
@@ -1716,7 +1910,7 @@ __global__ __launch_bounds__(192) void k_demod_pw(const DemodArgs a) {
         pre_wave(a, pre, static_cast<int>(threadIdx.x) - 64);
         return;
     }
-    demod_body<true, true>(a, pre, aux);
+    demod_dispatch<true, true>(a, pre, aux);
 }
 
 __global__ void k_init_state(ChanState* st, float* carry, float* sq_ring, float* ctcss_q, const ChanParams* cp, int nstreams, int nch,
