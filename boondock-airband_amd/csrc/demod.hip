@@ -69,9 +69,11 @@ using TyNfm = ChanType<MI_MOD_NFM, 1, 0, 0, -1, -1, 0>;       // NFM without
 // gate, axcindicate and the audio / raw-I/Q stores of those steps.  Nothing flows back except the final state at QUIT.
 constexpr unsigned kTokRing = 256;  // steps in flight (a power of two, >= 2 blocks)
 constexpr unsigned kDescRing = 32;
-enum : unsigned { AUX_BLOCK = 1, AUX_RESET = 2, AUX_BATCH = 3, AUX_QUIT = 4 };
+// (plain AM channels: a step's token is (squelch level, wavein[j], wavein[j - AGC_EXTRA]) instead of the filtered I/Q, and the two AM
+//  edges -- first_open_sample's bootstrap of agcavgfast and last_open_sample's fade, rtl_airband.cpp:554-569 -- are descriptors)
+enum : unsigned { AUX_BLOCK = 1, AUX_RESET = 2, AUX_BATCH = 3, AUX_QUIT = 4, AUX_FIRST_OPEN = 5, AUX_LAST_OPEN = 6 };
 struct AuxShare {
-    float tk_re[kTokRing], tk_im[kTokRing];
+    float tk_re[kTokRing], tk_im[kTokRing], tk_ax[kTokRing];
     unsigned d_word[kDescRing];  // type | n << 8
     unsigned d_arg[kDescRing];   // BLOCK: the first step's index; BATCH: the batch's index
     unsigned d_head;             // descriptors posted (channel wave)
@@ -160,7 +162,7 @@ __device__ __forceinline__ void set_state(Ctx& c, int update) {  // squelch.cpp:
     c.s.next_state = update;
 }
 
-__device__ __forceinline__ void aux_post(Ctx& c, unsigned type, unsigned n, unsigned arg, float re, float im);
+__device__ __forceinline__ void aux_post(Ctx& c, unsigned type, unsigned n, unsigned arg, float re, float im, float ax = 0.0f);
 __device__ __forceinline__ void ctcss_reset(Ctx& c) {  // CTCSS::reset on both detectors, ctcss.cpp:165-172
     if (!c.p.ctcss_enabled)
         return;
@@ -641,7 +643,7 @@ __device__ __forceinline__ unsigned aux_peek(const __attribute__((address_space(
     return __builtin_amdgcn_readfirstlane(*(const aux_vu32*)p);
 }
 // channel wave: one descriptor, with n tokens (lane m < n holds step arg + m; n == 1 from the sample loop: wave-uniform values)
-__device__ __forceinline__ void aux_post(Ctx& c, const unsigned type, const unsigned n, const unsigned arg, const float re, const float im) {
+__device__ __forceinline__ void aux_post(Ctx& c, const unsigned type, const unsigned n, const unsigned arg, const float re, const float im, const float ax) {
     LdsAux* const x = c.aux;
     for (unsigned spin = 0;; ++spin) {  // room in both rings (the audio wave is the faster one: normally no wait)
         const unsigned tt = aux_peek(&x->tk_tail), dt = aux_peek(&x->d_tail);
@@ -658,6 +660,8 @@ __device__ __forceinline__ void aux_post(Ctx& c, const unsigned type, const unsi
         const unsigned at = (c.tk_head + static_cast<unsigned>(c.lane)) & (kTokRing - 1u);
         *(aux_vf32*)&x->tk_re[at] = re;
         *(aux_vf32*)&x->tk_im[at] = im;
+        if (c.p.modulation == MI_MOD_AM)
+            *(aux_vf32*)&x->tk_ax[at] = ax;
     }
     if (c.lane == 0) {
         *(aux_vu32*)&x->d_word[c.d_head & (kDescRing - 1u)] = type | (n << 8);
@@ -979,8 +983,12 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
                 io.iqo[i0 + lane] = gate ? make_float2(re, im) : make_float2(0.0f, 0.0f);
         }
     }
-    if (do_audio && c.split)
-        aux_post(c, AUX_BLOCK, static_cast<unsigned>(kc), i0, re, im);
+    if (do_audio && c.split) {
+        if (P.modulation == MI_MOD_AM)
+            aux_post(c, AUX_BLOCK, static_cast<unsigned>(kc), i0, level, xf, ax);
+        else
+            aux_post(c, AUX_BLOCK, static_cast<unsigned>(kc), i0, re, im);
+    }
     if (own_audio && P.ctcss_enabled) {  // Squelch::process_audio_sample -> CTCSS::process_audio_sample (ctcss.cpp:124-135)
         const bool fast_too = !s.cs_enough;
         for (int m = 0; m < kc; m += 4) {  // kc is a multiple of 4
@@ -1156,7 +1164,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
     c.p = a.cp[ch];
     T::apply(c.p);
     const ChanParams& P = c.p;
-    c.split = kPre && a.audio_wave && P.modulation != MI_MOD_AM;  // (the audio wave decides the same way)
+    c.split = kPre && a.audio_wave && (P.modulation != MI_MOD_AM || TyAmPlain::matches(P));  // (the audio wave decides the same way)
     c.aux = aux;
     c.tk_head = c.d_head = 0;
     c.timeouts = a.pre_timeouts;
@@ -1382,7 +1390,22 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
                     process_filtered(c, x);
             }
 
-            if (am) {  // rtl_airband.cpp:554-569
+            if (am && c.split) {  // the audio wave's: it owns agcavgfast and the outputs the fade rewrites
+                if (c.s.current_state != SQ_OPEN && c.s.next_state == SQ_OPEN) {  // first_open_sample
+                    aux_post(c, AUX_FIRST_OPEN, 1u, i, squelch_level(c), 0.0f);  // (one token: the level)
+                } else if ((c.s.current_state == SQ_CLOSING && c.s.next_state == SQ_CLOSED) ||
+                           (c.s.current_state != SQ_LOW_SIGNAL_ABORT && c.s.next_state == SQ_LOW_SIGNAL_ABORT)) {  // last_open_sample
+                    // the fade rewrites the previous 99 outputs: those of the group's earlier steps that are this wave's (zeros) have to
+                    // be in memory first
+#pragma unroll
+                    for (int k = 0; k < m; ++k)
+                        if (!((posted >> k) & 1u))
+                            W(kAgcExtra + i0 + k) = pend[k];
+                    flushed = m;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    aux_post(c, AUX_LAST_OPEN, 0u, i, 0.0f, 0.0f);
+                }
+            } else if (am) {  // rtl_airband.cpp:554-569
                 if (c.s.current_state != SQ_OPEN && c.s.next_state == SQ_OPEN) {  // first_open_sample
                     for (int kk = 0; kk < kAgcExtra; ++kk) {
                         const float w = magrow[i + kk];
@@ -1406,7 +1429,10 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
 
             float wout = 0.0f;
             if (c.s.current_state == SQ_OPEN || c.s.current_state == SQ_CLOSING) {  // should_process_audio
-                if (am) {  // rtl_airband.cpp:575-585
+                if (am && c.split) {
+                    aux_post(c, AUX_BLOCK, 1u, i, squelch_level(c), x, ax);
+                    posted |= 1u << m;
+                } else if (am) {  // rtl_airband.cpp:575-585
                     if (x > squelch_level(c))
                         c.s.agcavgfast = c.s.agcavgfast * 0.995f + x * 0.005f;
                     wout = (ax - c.s.agcavgfast) / (c.s.agcavgfast * 1.5f);
@@ -1676,8 +1702,10 @@ __device__ __forceinline__ void audio_wave(const DemodArgs& a, LdsAux* x, const 
     const int row = static_cast<int>(blockIdx.x);
     const int stream = row / a.nch, ch = row - stream * a.nch;
     const ChanParams P = a.cp[ch];
-    if (!a.audio_wave || P.modulation == MI_MOD_AM)
+    const bool am = P.modulation == MI_MOD_AM;
+    if (!a.audio_wave || (am && !TyAmPlain::matches(P)))
         return;  // (the channel wave decides the same way and keeps everything)
+    const float* __restrict__ magrow = a.mag + static_cast<size_t>(row) * a.plane_stride;
     const ChanState& s0 = a.st[row];
     float agc = s0.agcavgfast, pr = s0.pr, pj = s0.pj, pw = s0.prev_waveout;
     float nx0 = s0.notch_x[0], nx1 = s0.notch_x[1], nx2 = s0.notch_x[2];
@@ -1716,7 +1744,72 @@ __device__ __forceinline__ void audio_wave(const DemodArgs& a, LdsAux* x, const 
         const unsigned word = aux_peek(&x->d_word[d_tail & (kDescRing - 1u)]);
         const unsigned arg = aux_peek(&x->d_arg[d_tail & (kDescRing - 1u)]);
         const unsigned type = word & 0xffu;
-        if (type == AUX_BLOCK) {
+        if (type == AUX_BLOCK && am) {
+            // AM AGC and audio (rtl_airband.cpp:574-585, 612-641; no CTCSS, no notch, no raw I/Q on these channels).  A clip --
+            // |waveout| > 0.8 -- feeds back into agcavgfast: the steps before the first one are final, the clipping step is taken
+            // by itself and the rest of the block follows as a unit of its own from the value it leaves.
+            int remaining = static_cast<int>(word >> 8);
+            unsigned off = 0;
+            while (remaining > 0) {
+                const int n = remaining;
+                const unsigned at = (tk_pos + off + static_cast<unsigned>(lane)) & (kTokRing - 1u);
+                const float level = *(aux_vf32*)&x->tk_re[at], xs = *(aux_vf32*)&x->tk_im[at], ax = *(aux_vf32*)&x->tk_ax[at];
+                const bool upd = xs > level;
+                const float bA = xs * 0.005f;
+                float G = 0.0f, Gp = agc;
+                MI_PASSES(0, n, {
+                    Gp = shr1(G, Gp);
+                    G = upd ? Gp * 0.995f + bA : Gp;
+                })
+                const float d = (ax - G) / (G * 1.5f);
+                const unsigned long long clipm = __ballot(lane < n && fabsf(d) > 0.8f);
+                const int k = clipm ? static_cast<int>(__builtin_ctzll(clipm)) : n;  // steps before the first clip
+                const int take = clipm ? k + 1 : n;
+                float out = (lane == k) ? d * 0.85f : d;
+                out *= P.ampfactor;
+                if (out != out)
+                    out = 0.0f;
+                else if (out > 1.0f)
+                    out = 1.0f;
+                else if (out < -1.0f)
+                    out = -1.0f;
+                batch_open = true;
+                if (lane < take) {
+                    const uint32_t v = kAgcExtra + arg + off + static_cast<uint32_t>(lane);
+                    float* dst = (v < nsteps) ? wmain + v : carry + (v - nsteps);
+                    *dst = out;
+                }
+                agc = clipm ? lane_read(G, k) * 1.15f : lane_read(G, n - 1);
+                off += static_cast<unsigned>(take);
+                remaining -= take;
+            }
+            tk_pos += word >> 8;
+            if (lane == 0)
+                *(aux_vu32*)&x->tk_tail = tk_pos;
+        } else if (type == AUX_FIRST_OPEN) {  // bootstrap of agcavgfast from the previous AGC_EXTRA magnitudes, rtl_airband.cpp:556-562
+            const float level = *(aux_vf32*)&x->tk_re[tk_pos & (kTokRing - 1u)];
+            tk_pos += 1u;
+            if (lane == 0)
+                *(aux_vu32*)&x->tk_tail = tk_pos;
+            const float w0 = magrow[arg + static_cast<unsigned>(lane)];
+            const float w1 = magrow[arg + 64u + static_cast<unsigned>(lane < kAgcExtra - 64 ? lane : 0)];
+            for (int kk = 0; kk < 64; ++kk) {
+                const float w = lane_read(w0, kk);
+                agc = (w >= level) ? agc * 0.9f + w * 0.1f : agc;
+            }
+            for (int kk = 0; kk < kAgcExtra - 64; ++kk) {
+                const float w = lane_read(w1, kk);
+                agc = (w >= level) ? agc * 0.9f + w * 0.1f : agc;
+            }
+        } else if (type == AUX_LAST_OPEN) {  // the fade of the previous AGC_EXTRA - 1 outputs, rtl_airband.cpp:564-568
+            auto W = [&](const uint32_t v) -> float* { return v < nsteps ? wmain + v : carry + (v - nsteps); };
+            float v = *W(arg);
+            for (int kk = 1; kk < kAgcExtra; ++kk) {
+                v = v * 0.94f;
+                if (lane == 0)
+                    *W(arg + static_cast<uint32_t>(kk)) = v;
+            }
+        } else if (type == AUX_BLOCK) {
             int remaining = static_cast<int>(word >> 8);
             unsigned off = 0;
             while (remaining > 0) {
