@@ -537,6 +537,8 @@ __device__ __forceinline__ void pre_period(float& F, float& C, float& T, float& 
 // values capped_ would have at the period ends -- full_'s (MERGED) or the previous period's cap (SATURATED) -- and one check of
 // every step's precondition under its own period's cap.  If it holds the values are the recurrence's; if not, nothing has been
 // taken and the periods are walked one by one.
+// kHaveF: full_ of the block's steps comes in F (the full_ wave of k_demod_pw walked it).
+template <bool kHaveF>
 __device__ __forceinline__ void pre_block(const ChanParams& P, float& nf, float& cap, const float full, const float capd, const uint32_t sc, const float x,
                                           const int kmax, const int lane, float& F, float& C, float& NFv, float& CAPv, int& zero_from) {
     const float k99 = 0.99f, n99 = static_cast<float>(1.0 - static_cast<double>(0.99f));
@@ -546,9 +548,11 @@ __device__ __forceinline__ void pre_block(const ChanParams& P, float& nf, float&
     zero_from = nb0 < kmax ? nb0 : 64;
     const bool merged = __float_as_uint(capd) == __float_as_uint(full);
     if (merged || capd >= cap * 0.96875f) {  // (SATURATED: the cap has risen a little with the noise floor since capped_ was set to it)
-        float Ft = 0.0f, T = full * k99;  // T: what lane 0 keeps reading (its shifted source does not exist)
-        for (int p_ = 0; p_ < kmax; p_ += 16)
-            full_passes16(Ft, T, b);
+        float Ft = kHaveF ? F : 0.0f, T = full * k99;  // T: what lane 0 keeps reading (its shifted source does not exist)
+        if (!kHaveF) {
+            for (int p_ = 0; p_ < kmax; p_ += 16)
+                full_passes16(Ft, T, b);
+        }
         float nf2 = nf, cap2 = cap, NF2 = nf, CAP2 = cap;
         for (int nb = nb0; nb < kmax; nb += 16) {  // calculate_noise_floor with capped_ as step nb-1 left it, squelch.cpp:477-490
             const float Cb = nb == 0 ? capd : (merged ? lane_read(Ft, nb - 1) : cap2);
@@ -615,6 +619,7 @@ struct PreShare {
     float C[kPreRing], F[kPreRing], NF[kPreRing], CAP[kPreRing];  // after step i, at i % kPreRing
     unsigned h_done;  // the pre-filter wave has delivered every step below this one
     unsigned m_pos;   // the channel wave is at (or past) this step
+    unsigned f_done;  // the full_ wave has delivered F of every step below this one
 };
 typedef __attribute__((address_space(3))) PreShare LdsPre;
 typedef __attribute__((address_space(3))) volatile unsigned pre_vu32;
@@ -786,7 +791,7 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     }
     if (!from_ring) {
         int zf = 64;
-        pre_block(P, nf, cap, s.pre_full, s.pre_capped, s.sample_count, x, kmax, lane, F, C, NFv, CAPv, zf);
+        pre_block<false>(P, nf, cap, s.pre_full, s.pre_capped, s.sample_count, x, kmax, lane, F, C, NFv, CAPv, zf);
         zero_from = min(zero_from, zf);
     }
     MI_PROF_MARK(0);
@@ -1615,12 +1620,50 @@ template <bool kUni>
 #define MI_UNI_BOUNDS __launch_bounds__(64)
 #endif
 #if MI_PW_EU > 0
-#define MI_PW_BOUNDS __launch_bounds__(192, MI_PW_EU)
+#define MI_PW_BOUNDS __launch_bounds__(256, MI_PW_EU)
 #else
-#define MI_PW_BOUNDS __launch_bounds__(192)
+#define MI_PW_BOUNDS __launch_bounds__(256)
 #endif
 __global__ MI_UNI_BOUNDS void k_demod(const DemodArgs a) {
     demod_dispatch<kUni, false>(a, nullptr, nullptr);
+}
+
+// The full_ wave of k_demod_pw: pre_filter_.full_ (squelch.cpp:505) of every step of the call -- a function of the raw magnitudes alone and
+// the longest dependent chain of the pre-filter pair (two operations per step; the noise floor and, outside the decays, capped_ follow
+// from it in a few operations per period).  Walked here on its own, 64 steps per trip, it sets the pace the pre-filter wave used to.
+__device__ __forceinline__ void full_wave(const DemodArgs& a, LdsPre* pre, const int lane) {
+    const int row = static_cast<int>(blockIdx.x);
+    const float* __restrict__ xrow = a.mag + static_cast<size_t>(row) * a.plane_stride + kAgcExtra;
+    const uint32_t n = a.nsteps;
+    const float k99 = 0.99f, n99 = static_cast<float>(1.0 - static_cast<double>(0.99f));
+    float full = a.st[row].pre_full;
+    float xn = xrow[min(static_cast<uint32_t>(lane), n - 1u)];  // the next block's samples, requested a block ahead
+    uint32_t reach = 0;  // steps below this are within the ring's reach of the channel wave as last seen
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+        const int kmax = static_cast<int>(min(64u, n - i0));
+        if (i0 + 64u > reach) {
+            for (unsigned idle = 0;; ++idle) {
+                reach = pre_peek(&pre->m_pos) + (kPreRing - 64u);
+                if (i0 + 64u <= reach)
+                    break;
+                __builtin_amdgcn_s_sleep(2);
+                if (idle > 4u * kPreSpin)
+                    return;  // (the channel wave is gone or stuck)
+            }
+        }
+        const float x = xn;
+        xn = xrow[min(i0 + 64u + static_cast<uint32_t>(lane), n - 1u)];
+        const float b = x * n99;
+        float F = 0.0f, T = full * k99;  // T: what lane 0 keeps reading (its shifted source does not exist)
+        for (int p_ = 0; p_ < kmax; p_ += 16)
+            full_passes16(F, T, b);
+        if (lane < kmax)
+            *(pre_vf32*)&pre->F[(i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u)] = F;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring values before the mark (see pre_wave)
+        if (lane == 0)
+            *(pre_vu32*)&pre->f_done = i0 + static_cast<uint32_t>(kmax);
+        full = lane_read(F, kmax - 1);
+    }
 }
 
 // The pre-filter wave of k_demod_pw: the recurrence of steady_block()'s first phase, block after block over the whole call.
@@ -1634,20 +1677,12 @@ __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const 
     float nf = s0.noise_floor, cap = s0.moving_avg_cap, full = s0.pre_full, capd = s0.pre_capped;
     uint32_t sc = s0.sample_count;
     float xn = xrow[min(static_cast<uint32_t>(lane), n - 1u)];  // the next block's samples, requested a block ahead
-    unsigned idle = 0;
 #ifdef MI_BLOCK_PROF
     unsigned long long pw_t0 = __builtin_readcyclecounter(), pw_wait = 0, pw_load = 0, pw_per = 0, pw_tail = 0, pw_fast = 0, pw_n = 0;
 #endif
     for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
         const int kmax = static_cast<int>(min(64u, n - i0));
-        // stay within the ring's reach of the channel wave (it posts its position before it waits for this wave)
-        while (i0 + 64u > pre_peek(&pre->m_pos) + (kPreRing - 64u)) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++idle > 4u * kPreSpin) {
-                return;  // (the channel wave is gone or stuck: it computes its own values when its wait runs out)
-            }
-        }
-        idle = 0;
+        // (the full_ wave stays within the ring's reach of the channel wave, and this wave behind the full_ wave)
 #ifdef MI_BLOCK_PROF
         unsigned long long pw_a = __builtin_readcyclecounter();
         pw_wait += pw_a - pw_t0;
@@ -1659,16 +1694,24 @@ __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const 
         pw_load += pw_b - pw_a;
 #endif
         xn = xrow[min(i0 + 64u + static_cast<uint32_t>(lane), n - 1u)];
-        float F, C, NFv, CAPv;
+        // full_ of these steps from the full_ wave (usually blocks ahead)
+        for (unsigned spin = 0; pre_peek(&pre->f_done) < i0 + static_cast<uint32_t>(kmax); ++spin) {
+            __builtin_amdgcn_s_sleep(1);
+            if (spin > 4u * kPreSpin)
+                return;
+        }
+        asm volatile("" ::: "memory");
+        float F = *(pre_vf32*)&pre->F[(i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u)];
+        float C, NFv, CAPv;
         int zf;
-        pre_block(P, nf, cap, full, capd, sc, x, kmax, lane, F, C, NFv, CAPv, zf);
+        pre_block<true>(P, nf, cap, full, capd, sc, x, kmax, lane, F, C, NFv, CAPv, zf);
 #ifdef MI_BLOCK_PROF
         unsigned long long pw_c = __builtin_readcyclecounter();
         pw_per += pw_c - pw_b;
 #endif
         if (lane < kmax) {
             const unsigned at = (i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u);
-            *(pre_vf32*)&pre->C[at] = C, *(pre_vf32*)&pre->F[at] = F, *(pre_vf32*)&pre->NF[at] = NFv, *(pre_vf32*)&pre->CAP[at] = CAPv;
+            *(pre_vf32*)&pre->C[at] = C, *(pre_vf32*)&pre->NF[at] = NFv, *(pre_vf32*)&pre->CAP[at] = CAPv;  // (F is there already)
         }
         // The ring values before the mark.  A wave's LDS operations are issued and executed in order, so the compiler barrier is what
         // matters; the wait makes the order explicit at the price of the LDS counter only (a workgroup fence would also wait for
@@ -1980,8 +2023,8 @@ __device__ __forceinline__ void audio_wave(const DemodArgs& a, LdsAux* x, const 
         *(aux_vu32*)&x->done = 1u;
 }
 
-// One channel per workgroup of three waves: the channel itself (as k_demod<true>), the pre-filter wave ahead of it and, behind it,
-// the audio wave of an NFM channel.
+// One channel per workgroup of four waves: the channel itself (as k_demod<true>), the full_ wave and the pre-filter wave ahead of it
+// and, behind it, the audio wave.
 struct PwShare {
     PreShare pre;
     AuxShare aux;
@@ -1991,10 +2034,14 @@ __global__ MI_PW_BOUNDS void k_demod_pw(const DemodArgs a) {
     LdsPre* const pre = (LdsPre*)&sh_mem.pre;
     LdsAux* const aux = (LdsAux*)&sh_mem.aux;
     if (threadIdx.x == 0) {
-        pre->h_done = 0, pre->m_pos = 0;
+        pre->h_done = 0, pre->m_pos = 0, pre->f_done = 0;
         aux->d_head = 0, aux->d_tail = 0, aux->tk_tail = 0, aux->done = 0;
     }
     __syncthreads();
+    if (threadIdx.x >= 192) {
+        full_wave(a, pre, static_cast<int>(threadIdx.x) - 192);
+        return;
+    }
     if (threadIdx.x >= 128) {
         audio_wave(a, aux, static_cast<int>(threadIdx.x) - 128);
         return;
@@ -2075,7 +2122,7 @@ hipError_t launch_demod(const DemodArgs& a, hipStream_t s) {
         return hipSuccess;
     const int blocks = (rows + a.lanes_per_wave - 1) / a.lanes_per_wave;
     if (a.lanes_per_wave == 1 && a.pre_wave && a.steady_blocks)
-        hipLaunchKernelGGL(k_demod_pw, dim3(blocks), dim3(192), 0, s, a);
+        hipLaunchKernelGGL(k_demod_pw, dim3(blocks), dim3(256), 0, s, a);
     else if (a.lanes_per_wave == 1)
         hipLaunchKernelGGL(k_demod<true>, dim3(blocks), dim3(64), 0, s, a);
     else
