@@ -1080,6 +1080,82 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
     } while (0)
 
 
+// The idle channel (k_demod_pw): CLOSED for recent_sample_size_ samples and more with no recent opening.  A step then moves nothing but
+// the pre-filter averages and the noise floor -- the pre-filter wave's work -- the squelch ring and the counters: update_current_state
+// clears the level cache at every step (squelch.cpp:442-449: closed_sample_count_ == recent_sample_size_), so the level of a step is
+// normal_signal_ratio_ x its own noise floor, and the step stays CLOSED iff capped_ < level (has_signal() is has_pre_filter_signal():
+// using_post_filter_ is off in CLOSED).  So a block is: two ring values per lane, one compare, the stores (zeros, the squelch ring of
+// a low-pass channel), and the state after its last step read from the ring -- no sample is loaded at all.  Same decisions and the
+// same state as steady_block<kPre, SQ_CLOSED> leaves, which takes over (with the sample loop) as soon as a step wants to open.
+__device__ __forceinline__ void idle_streak(Ctx& c, const DemodArgs& a, BlockIo& bio, uint32_t& gi, const uint32_t ngroups, uint32_t& in_batch, uint32_t& batch,
+                                            bool& batch_open, int& skip, bool& stale, LdsPre* pre, bool& pre_on, const int row) {
+    ChanState& s = c.s;
+    const ChanParams& P = c.p;
+    const int lane = c.lane;
+    for (;;) {
+        int kmax = min(64, static_cast<int>(ngroups - gi) * 4);
+        kmax = min(kmax, kWaveBatch - static_cast<int>(in_batch));  // the batch flag is written at a batch's last step
+        const int phase = static_cast<int>((__builtin_amdgcn_readfirstlane(s.sample_count) + 1u) & 15u);
+        if (phase && kmax == 64)
+            kmax = 64 - phase;  // end on a multiple of 16 of sample_count_, like every steady block
+        kmax &= ~3;
+        if (kmax < 8)
+            return;  // the sample loop takes this group
+        const uint32_t i0 = gi * 4;
+        if (!pre_wait(pre, lane, i0, i0 + static_cast<uint32_t>(kmax))) {
+            pre_on = false;  // (final: see steady_block)
+            if (lane == 0 && a.pre_timeouts)
+                atomicAdd(a.pre_timeouts, 1u);
+            return;
+        }
+        const unsigned at = (i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u);
+        const float C = *(pre_vf32*)&pre->C[at], NFv = *(pre_vf32*)&pre->NF[at];
+        const float level = P.using_manual_level ? P.manual_signal_level : P.normal_signal_ratio * NFv;
+        const unsigned long long actmask = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
+        const unsigned long long failm = __ballot(C >= level) & actmask;
+        const int k = failm ? static_cast<int>(__builtin_ctzll(failm)) : kmax;
+        const int kc = k & ~3;
+        if (kc == 0) {
+            skip = 4;
+            return;
+        }
+        const int last = kc - 1;
+        if (lane < kc) {
+            if (P.lowpass_enabled) {
+                int h = s.buffer_head + 1 + lane;
+                h = h >= kSquelchRing ? h - kSquelchRing : h;
+                c.ring[h] = C * 0.9f;
+            }
+            const uint32_t v = kAgcExtra + i0 + static_cast<uint32_t>(lane);
+            float* dst = (v < bio.n) ? bio.wmain + v : bio.carry + (v - bio.n);
+            *dst = 0.0f;
+            if (bio.has_iqo)
+                bio.iqo[i0 + static_cast<uint32_t>(lane)] = make_float2(0.0f, 0.0f);
+        }
+        // the state after step `last`
+        const unsigned atl = (i0 + static_cast<uint32_t>(last)) & (kPreRing - 1u);
+        s.noise_floor = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->NF[atl])));
+        s.moving_avg_cap = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->CAP[atl])));
+        s.pre_full = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->F[atl])));
+        s.pre_capped = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->C[atl])));
+        s.squelch_level_cache = P.using_manual_level ? 0.0f : P.normal_signal_ratio * s.noise_floor;
+        s.sample_count += static_cast<uint32_t>(kc);
+        s.buffer_head = s.buffer_head + kc >= kSquelchRing ? s.buffer_head + kc - kSquelchRing : s.buffer_head + kc;
+        s.buffer_tail = s.buffer_tail + kc >= kSquelchRing ? s.buffer_tail + kc - kSquelchRing : s.buffer_tail + kc;
+        in_batch += static_cast<uint32_t>(kc);
+        if (in_batch == kWaveBatch)
+            MI_END_BATCH();
+        gi += static_cast<uint32_t>(kc / 4);
+        stale = true;  // the group fetched ahead is behind us now
+        if (kc != kmax) {
+            skip = 4;
+            return;
+        }
+        if (gi >= ngroups)
+            return;
+    }
+}
+
 // A run of steady blocks in one state (current_state_ == next_state_ == kSt, or whatever it is for kSt < 0): a block never changes
 // the state, so while blocks commit in full nothing but their lengths has to be worked out between them -- the batch end, the
 // 16-step phase of sample_count_, and in the waiting states the step whose delay_ decides.  Returns with gi at the first group no
@@ -1241,7 +1317,10 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
                   const int st = __builtin_amdgcn_readfirstlane(c.s.current_state);
                   const int nxt = __builtin_amdgcn_readfirstlane(c.s.next_state);
                   if (st == nxt) {  // (a branch on the state here, and the blocks' own tests of it fold away)
-                      if (st == SQ_CLOSED)
+                      if (kPre && st == SQ_CLOSED && pre_on && __builtin_amdgcn_readfirstlane(c.s.closed_sample_count) == kRecentSampleSize &&
+                          __builtin_amdgcn_readfirstlane(c.s.recent_open_count) == 0u)
+                          idle_streak(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
+                      else if (st == SQ_CLOSED)
                           steady_streak<kPre, SQ_CLOSED>(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
                       else if (st == SQ_OPEN)
                           steady_streak<kPre, SQ_OPEN>(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
@@ -1612,7 +1691,7 @@ template <bool kUni>
 #define MI_UNI_EU 3
 #endif
 #ifndef MI_PW_EU
-#define MI_PW_EU 2
+#define MI_PW_EU 1
 #endif
 #if MI_UNI_EU > 0
 #define MI_UNI_BOUNDS __launch_bounds__(64, MI_UNI_EU)
@@ -1639,6 +1718,9 @@ __device__ __forceinline__ void full_wave(const DemodArgs& a, LdsPre* pre, const
     float full = a.st[row].pre_full;
     float xn = xrow[min(static_cast<uint32_t>(lane), n - 1u)];  // the next block's samples, requested a block ahead
     uint32_t reach = 0;  // steps below this are within the ring's reach of the channel wave as last seen
+#ifdef MI_BLOCK_PROF
+    unsigned long long fw_t = __builtin_readcyclecounter(), fw_reach = 0, fw_load = 0, fw_chain = 0, fw_tail = 0, fw_n = 0;
+#endif
     for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
         const int kmax = static_cast<int>(min(64u, n - i0));
         if (i0 + 64u > reach) {
@@ -1651,19 +1733,43 @@ __device__ __forceinline__ void full_wave(const DemodArgs& a, LdsPre* pre, const
                     return;  // (the channel wave is gone or stuck)
             }
         }
-        const float x = xn;
+#ifdef MI_BLOCK_PROF
+        unsigned long long fw_a = __builtin_readcyclecounter();
+        fw_reach += fw_a - fw_t;
+#endif
+        float x = xn;
+        asm volatile("" : "+v"(x));
+#ifdef MI_BLOCK_PROF
+        unsigned long long fw_b = __builtin_readcyclecounter();
+        fw_load += fw_b - fw_a;
+#endif
         xn = xrow[min(i0 + 64u + static_cast<uint32_t>(lane), n - 1u)];
         const float b = x * n99;
         float F = 0.0f, T = full * k99;  // T: what lane 0 keeps reading (its shifted source does not exist)
         for (int p_ = 0; p_ < kmax; p_ += 16)
             full_passes16(F, T, b);
+#ifdef MI_BLOCK_PROF
+        asm volatile("" : "+v"(F));
+        unsigned long long fw_c = __builtin_readcyclecounter();
+        fw_chain += fw_c - fw_b;
+#endif
         if (lane < kmax)
             *(pre_vf32*)&pre->F[(i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u)] = F;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ring values before the mark (see pre_wave)
         if (lane == 0)
             *(pre_vu32*)&pre->f_done = i0 + static_cast<uint32_t>(kmax);
         full = lane_read(F, kmax - 1);
+#ifdef MI_BLOCK_PROF
+        fw_t = __builtin_readcyclecounter();
+        fw_tail += fw_t - fw_c;
+        ++fw_n;
+#endif
     }
+#ifdef MI_BLOCK_PROF
+    if (lane == 0 && (row == 0 || row == 5))
+        printf("fullprof row %d: %llu blocks; per block: reach check %llu, sample wait %llu, chain %llu, ring + mark %llu\n", row, fw_n, fw_reach / fw_n, fw_load / fw_n, fw_chain / fw_n,
+               fw_tail / fw_n);
+#endif
 }
 
 // The pre-filter wave of k_demod_pw: the recurrence of steady_block()'s first phase, block after block over the whole call.
@@ -1701,6 +1807,13 @@ __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const 
                 return;
         }
         asm volatile("" ::: "memory");
+#ifdef MI_BLOCK_PROF
+        {
+            const unsigned long long t_ = __builtin_readcyclecounter();
+            pw_fast += t_ - pw_b;
+            pw_b = t_;
+        }
+#endif
         float F = *(pre_vf32*)&pre->F[(i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u)];
         float C, NFv, CAPv;
         int zf;
@@ -1731,8 +1844,8 @@ __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const 
     }
 #ifdef MI_BLOCK_PROF
     if (lane == 0 && (row == 0 || row == 5))
-        printf("preprof row %d: %llu blocks; per block: throttle %llu, sample wait %llu, periods %llu, ring + state %llu\n", row, pw_n, pw_wait / pw_n, pw_load / pw_n,
-               pw_per / pw_n, pw_tail / pw_n);
+        printf("preprof row %d: %llu blocks; per block: loop head %llu, sample wait %llu, wait for full_ %llu, floor + capped_ %llu, ring + state %llu\n", row, pw_n, pw_wait / pw_n,
+               pw_load / pw_n, pw_fast / pw_n, pw_per / pw_n, pw_tail / pw_n);
 #endif
 }
 

@@ -112,7 +112,7 @@ struct mi_demod {
     int opt_tp_chunks = 0;    // MI_OPT_TP_CHUNKS: 0 = measured default
     double opt_tp_ratio = 0;  // MI_OPT_TP_RATIO_PCT / 100: 0 = measured default
     int opt_tp_lpw = 0;       // MI_OPT_TP_SEG_LANES: lanes per wave of the segment pass, 0 = auto
-    int opt_pre_wave = -1;       // MI_OPT_PRE_WAVE: serial kernel, one channel per wave: a second wave walks the squelch pre-filter ahead (k_demod_pw); -1 = up to 512 rows
+    int opt_pre_wave = -1;       // MI_OPT_PRE_WAVE: serial kernel, one channel per wave: further waves per channel walk the squelch pre-filter ahead and the audio behind (k_demod_pw); -1 = up to 256 rows
     bool opt_audio_wave = true;  // MI_OPT_AUDIO_WAVE: ... and NFM channels a third wave for everything behind the filtered I/Q (audio, CTCSS, gate, stores)
     bool opt_spec_head = true;   // MI_OPT_SPEC_HEAD: overlapped calls start their first segments from a guessed state (see TpArgs)
     int opt_tp_eager = 0;        // (diagnostic, MI_AIRBAND_TP_EAGER)
@@ -431,7 +431,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     // the pre-filter wave pays where a call is bound by the latency of its rows (4 / 8 / 16 streams x 32 mixed channels: +44 / +37 /
     // +12 %); with a thousand rows and more the machine is full and a second wave per row only takes LDS and issue slots from
     // stage 1 (32 streams: +-0, 64 streams: -27 %)
-    da.pre_wave = (h->opt_pre_wave < 0 ? h->rows <= 512 : h->opt_pre_wave != 0) ? 1 : 0;
+    // (round 3: four waves per channel, each with a SIMD's register file to itself: one channel per CU, so up to 256 rows)
+    da.pre_wave = (h->opt_pre_wave < 0 ? h->rows <= 256 : h->opt_pre_wave != 0) ? 1 : 0;
     da.audio_wave = h->opt_audio_wave ? 1 : 0;
     da.pre_timeouts = h->d_pre_timeouts;
 

@@ -267,9 +267,10 @@ enum {
     MI_OPT_SPEC_HEAD = 13,    /* 1 (default): when consecutive calls overlap (MI_OPT_EARLY_INPUT, alternating audio buffers) the first segments
                                * of a call warm up on the previous call's samples from a guessed state, as all others do, instead of waiting
                                * for the state that call's tail leaves; the scan checks them against it afterwards */
-    MI_OPT_PRE_WAVE = 14,     /* serial stage 2 with one channel per wave: a second wave per channel walks the squelch's pre-filter averages and
-                               * noise floor over the call ahead of the channel's own wave (demod.hip, k_demod_pw).  -1 (default): up to 512
-                               * rows (streams x channels), 0 never, 1 always */
+    MI_OPT_PRE_WAVE = 14,     /* serial stage 2 with one channel per wave: further waves of the channel's workgroup walk the squelch's pre-filter
+                               * averages and noise floor over the call ahead of the channel's own wave (demod.hip, k_demod_pw: the full_ wave
+                               * and the pre-filter wave).  -1 (default): up to 256 rows (streams x channels: one channel per CU), 0 never,
+                               * 1 always */
     MI_OPT_RESERVE_CUS = 15,  /* time-parallel path: the wide passes of a call (stage 1, aggregates, segment pass) keep off this many CUs, which stay
                                * free for the core chains and the latency-bound tail kernels of the neighbouring calls (they need few waves but
                                * most of a SIMD's registers each, and otherwise wait for a wide wave to retire).  -1 (default): 32 on handles of
