@@ -537,7 +537,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
     const uint32_t bps_log = 31u - static_cast<uint32_t>(__builtin_clz(bps));
 
     int n_run = 0, n_single = 0, n_step = 0, n_fail = 0;  // diagnostics: blocks per path, failed hypotheses
-    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_wait = 0, t_stepping = 0, t_mark = 0; int n_waits = 0, n_from_rec = 0, n_reclook = 0; unsigned long long t_recwait = 0;)
+    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_wait = 0, t_stepping = 0, t_mark = 0; int n_waits = 0, n_from_rec = 0, n_reclook = 0, n_fast4 = 0; unsigned long long t_recwait = 0;)
     // kSplit: the noise-floor passes come from the chain wave (CoreShare).  `own`: this wave advanced the noise floor itself since it
     // last took a value from there (single blocks, decays): the next value taken is only good if the chain wave agrees on the one
     // before it.  `solo`: the chain wave was given up on (a wait ran out): from then on this wave walks the chain itself.
@@ -553,6 +553,75 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
     }
     uint32_t fetch_seen = a.blk0;  // kSplit: blocks whose aggregates the fetch waves are known to have delivered
     for (uint32_t g0 = a.blk0; g0 < nblk; g0 += 64) {
+        if (kSplit && !solo && !own && g0 + 256u <= nblk) {
+            // ---- four groups in one regime at once.  Under the hypothesis that the regime persists every block's check depends on ring
+            // values alone (the state entering a block is the noise floor the chain wave left for the block before, full_ at its
+            // start, and capped_ == full_ or == the cap), so 256 blocks are judged by one pass of straight-line code and one branch:
+            // the control flow around a group costs a lone wave as much as its arithmetic (tools/micro/branch_cost.hip).  Anything
+            // else -- a block that fails, rings not filled that far yet -- is left to the group-by-group paths below.
+            nf = uni(nf), cap = uni(cap), c = uni(c), full = uni(full);
+            const bool merged = (c == full);
+            if (merged || c == cap) {
+                if (fetch_seen < g0 + 257u)
+                    fetch_seen = min(share_peek(&sh->fetch_next[0]), share_peek(&sh->fetch_next[1]));
+                if (done_seen < g0 + 256u)
+                    done_seen = max(done_seen, share_peek(&sh->w0_done));
+                if (fetch_seen >= g0 + 257u && done_seen >= g0 + 256u) {
+                    share_order();
+                    if (lane == 0)
+                        share_post(&sh->w1_pos, g0);
+                    bool ok = true;
+                    float q_nfp[4], q_capp[4], q_ce[4], q_fe[4], vnf3 = 0.0f, fe3 = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t b = g0 + 64u * static_cast<uint32_t>(j) + static_cast<uint32_t>(lane);
+                        const bool head = j == 0 && lane == 0;  // the block this wave's own state enters
+                        const float vnf = *(lds_vf32*)&sh->nfring[b & (kNfRing - 1u)];
+                        const float nfp_r = *(lds_vf32*)&sh->nfring[(b - 1u) & (kNfRing - 1u)];
+                        const float fep_r = *(lds_vf32*)&sh->opring[b & (kOpRing - 1u)];
+                        const float fe = *(lds_vf32*)&sh->opring[(b + 1u) & (kOpRing - 1u)];
+                        const float fm = *(lds_vf32*)&sh->fmring[b & (kOpRing - 1u)];
+                        const float x0 = *(lds_vf32*)&sh->x0ring[b & (kOpRing - 1u)];
+                        const float xm = *(lds_vf32*)&sh->xmring[b & (kOpRing - 1u)];
+                        const float nf_prev = head ? nf : nfp_r;
+                        const float cap_prev = head ? cap : cap_of(p, nf_prev);
+                        const float capj = cap_of(p, vnf);
+                        const float full_entry = head ? full : fep_r;
+                        const float c_entry = merged ? full_entry : cap_prev;
+                        const float opw = head ? fe_group : fep_r;
+                        ok = ok && fm >= 0.0f && __builtin_fminf(c_entry, nf_prev) == __builtin_fminf(opw, nf_prev);
+                        if (merged)
+                            ok = ok && c_entry < capj && fm < capj;
+                        else
+                            ok = ok && capped_step(c_entry, x0, capj) == capj && xm >= capj;
+                        q_nfp[j] = nf_prev, q_capp[j] = cap_prev, q_ce[j] = c_entry, q_fe[j] = full_entry;
+                        if (j == 3)
+                            vnf3 = vnf, fe3 = fe;
+                    }
+                    if (__ballot(ok) == ~0ull) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t bj = g0 + 64u * static_cast<uint32_t>(j) + static_cast<uint32_t>(lane);
+                            if ((bj & (bps - 1u)) == 0) {  // the state at a segment boundary
+                                TpCore t;
+                                t.nf = q_nfp[j], t.cap = q_capp[j], t.c = q_ce[j], t.full = q_fe[j];
+                                core[bj >> bps_log] = t;
+                            }
+                        }
+                        nf = rl(vnf3, 63);
+                        cap = cap_of(p, nf);
+                        full = rl(fe3, 63);
+                        c = merged ? full : cap;
+                        n_run += 256;
+                        ++n_single;
+                        CORE_PROF(++n_fast4;)
+                        fe_group = full;
+                        g0 += 192u;
+                        continue;
+                    }
+                }
+            }
+        }
         CoreGroup cur;
         float fe_prev;  // full_ at the start of lane's block, valid for lane > kk
         if (kSplit) {
@@ -929,8 +998,8 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
         }
         fe_group = rl(cur.fe, 63);
     }
-    CORE_PROF(if (lane == 0 && r < 8) printf("core w1 row %d: total %llu us  wait-w0 %llu us (%d waits)  stepping %llu us (record waits %llu us, %d looks)  run %d accepted-runs %d step %d (from records %d) fail %d rollback %d solo %d\n", r,
-                                           (prof_now() - t_begin) / 100, t_wait / 100, n_waits, t_stepping / 100, t_recwait / 100, n_reclook, n_run, n_single, n_step, n_from_rec, n_fail, n_rollback, (int)solo);)
+    CORE_PROF(if (lane == 0 && r < 8) printf("core w1 row %d: total %llu us  wait-w0 %llu us (%d waits)  stepping %llu us (record waits %llu us, %d looks)  run %d accepted-runs %d step %d (from records %d) fail %d rollback %d solo %d fast4 %d\n", r,
+                                           (prof_now() - t_begin) / 100, t_wait / 100, n_waits, t_stepping / 100, t_recwait / 100, n_reclook, n_run, n_single, n_step, n_from_rec, n_fail, n_rollback, (int)solo, n_fast4);)
     if (kSplit && lane == 0)
         share_post(&sh->quit, 1u);
     if (lane == 0) {

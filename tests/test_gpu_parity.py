@@ -862,6 +862,43 @@ def test_pre_filter_wave_same_bits_and_state(pkg, seed, per_call):
     assert_same(wo[0], owo, "audio vs oracle")
 
 
+@pytest.mark.parametrize("seed,per_call", [(0xA1B2C3D4, 4), (77, 1), (5, 12)])
+def test_audio_wave_same_bits_and_state(pkg, seed, per_call):
+    """MI_OPT_AUDIO_WAVE (k_demod_pw): everything behind the squelch decisions -- NFM discriminator, DC block, de-emphasis, the CTCSS
+    detector banks with their windows and counters, output gate, notch filter, axcindicate, the audio / raw-I/Q stores; for plain AM
+    channels the AGC with its clip feedback, the open-edge bootstrap and the close-edge fade -- runs on a wave of its own, fed by the
+    channel's wave through a token ring in LDS (demod.hip, audio_wave).  On and off over the channel zoo in calls of 1, 4 and 12
+    batches: audio, flags, raw I/Q, statistics and the complete checkpoint state are identical, and equal to the oracle."""
+    centre, chans = _channel_zoo(pkg)
+    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=9)
+    nbat = 12
+    iq = _zoo_capture(pkg, dev, centre, chans, nbat, seed)
+    res = {}
+    for on in (1, 0):
+        d = pkg.Demod(dev, chans, max_batches=per_call)
+        d.set_option(pkg.OPT_PRE_WAVE, 1)
+        d.set_option(pkg.OPT_AUDIO_WAVE, on)
+        outs = []
+        for call in range(nbat // per_call):
+            pos = (call * per_call * WAVE_BATCH) * d.hop_bytes if call == 0 else (call * per_call * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+            wo, axc, iqo, _ = d.process([iq[pos:]], per_call, want_iq=True)
+            outs.append((wo.copy(), axc.copy(), iqo.copy(), bytes(d.stats()), d.get_state().copy()))
+        assert d.pre_wave_timeouts() == 0, "a wave of a channel's workgroup gave up waiting for another"
+        d.close()
+        res[on] = outs
+    for call, (a, b) in enumerate(zip(res[1], res[0])):
+        assert_same(a[0], b[0], f"audio, call {call}")
+        assert_same(a[1], b[1], f"flags, call {call}")
+        assert_same(a[2], b[2], f"raw I/Q, call {call}")
+        assert a[3] == b[3], f"statistics differ after call {call}"
+        assert_same(a[4], b[4], f"checkpoint state, call {call}")
+    nb, owo, oaxc, oiq = oracle_run(dev, chans, iq, nbat, want_iq=True)
+    wo = np.concatenate([o[0][:, :, :per_call * WAVE_BATCH] for o in res[1]], axis=2)
+    axc = np.concatenate([o[1] for o in res[1]], axis=2)
+    assert_same(axc[0], oaxc, "flags vs oracle")
+    assert_same(wo[0], owo, "audio vs oracle")
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_steady_blocks_random_plans(pkg, seed):
     """Random channel plans and captures (modulation, low-pass, notch, CTCSS, manual / SNR squelch thresholds down to 0 dB,
