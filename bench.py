@@ -246,7 +246,7 @@ def traffic_of(traffic, name):
     k_channelize9p or k_channelize<...> depending on the plan and the options."""
     b = name.split("#")[0]
     alias = {"k_channelize": ("k_channelize", "l64_entry", "k_channelize9p"), "k_tp_core": ("k_tp_core", "k_tp_core2"),  # (k_tp_core2: the split chain)
-             "k_demod": ("k_demod_pw", "k_demod")}                                                                    # (k_demod_pw: with the pre-filter wave)
+             "k_demod": ("k_demod_pw", "k_demod_uni", "k_demod_packed", "k_demod")}                                   # (k_demod_pw: four waves per channel)
     for k in alias.get(b, (b,)):
         if k in traffic:
             return traffic[k]

@@ -1686,25 +1686,33 @@ __device__ __forceinline__ void demod_dispatch(const DemodArgs& a, LdsPre* pre, 
         demod_body<kUni, kPre, TyAny>(a, pre, aux);
     }
 }
-template <bool kUni>
+// Register budgets (waves per SIMD the kernels are compiled for; diagnostic builds override them: make EXTRA=-DMI_UNI_EU=3).
+//   k_demod_uni    one channel per wave, thousands of rows: 128 registers.  It spills (1.3 KB of scratch per lane), and still the
+//                  rows are no slower (1.23 vs 1.30 ms per 2 s at 2 048 rows) -- and BASELINE configs[3] gains a fifth (146 -> 181 GS/s):
+//                  the kernel shares every SIMD with stage 1 of the next call (167 registers a wave), and what the two can hold
+//                  there together is what bounds the step.  96 registers and fewer: the spills take over
+//                  (1.9 / 3.8 / 2.7 ms at 96 / 80 / 64).
+//   k_demod_packed several channels per wave (more than MI_OPT_UNI_ROWS rows): 168, as measured in round 2.
+//   k_demod_pw     four waves per channel, one channel per CU: a SIMD's whole register file each.
 #ifndef MI_UNI_EU
-#define MI_UNI_EU 3
+#define MI_UNI_EU 4
+#endif
+#ifndef MI_PACKED_EU
+#define MI_PACKED_EU 3
 #endif
 #ifndef MI_PW_EU
 #define MI_PW_EU 1
-#endif
-#if MI_UNI_EU > 0
-#define MI_UNI_BOUNDS __launch_bounds__(64, MI_UNI_EU)
-#else
-#define MI_UNI_BOUNDS __launch_bounds__(64)
 #endif
 #if MI_PW_EU > 0
 #define MI_PW_BOUNDS __launch_bounds__(256, MI_PW_EU)
 #else
 #define MI_PW_BOUNDS __launch_bounds__(256)
 #endif
-__global__ MI_UNI_BOUNDS void k_demod(const DemodArgs a) {
-    demod_dispatch<kUni, false>(a, nullptr, nullptr);
+__global__ __launch_bounds__(64, MI_UNI_EU) void k_demod_uni(const DemodArgs a) {
+    demod_dispatch<true, false>(a, nullptr, nullptr);
+}
+__global__ __launch_bounds__(64, MI_PACKED_EU) void k_demod_packed(const DemodArgs a) {
+    demod_dispatch<false, false>(a, nullptr, nullptr);
 }
 
 // The full_ wave of k_demod_pw: pre_filter_.full_ (squelch.cpp:505) of every step of the call -- a function of the raw magnitudes alone and
@@ -2136,7 +2144,7 @@ __device__ __forceinline__ void audio_wave(const DemodArgs& a, LdsAux* x, const 
         *(aux_vu32*)&x->done = 1u;
 }
 
-// One channel per workgroup of four waves: the channel itself (as k_demod<true>), the full_ wave and the pre-filter wave ahead of it
+// One channel per workgroup of four waves: the channel itself (as k_demod_uni), the full_ wave and the pre-filter wave ahead of it
 // and, behind it, the audio wave.
 struct PwShare {
     PreShare pre;
@@ -2237,9 +2245,9 @@ hipError_t launch_demod(const DemodArgs& a, hipStream_t s) {
     if (a.lanes_per_wave == 1 && a.pre_wave && a.steady_blocks)
         hipLaunchKernelGGL(k_demod_pw, dim3(blocks), dim3(256), 0, s, a);
     else if (a.lanes_per_wave == 1)
-        hipLaunchKernelGGL(k_demod<true>, dim3(blocks), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_demod_uni, dim3(blocks), dim3(64), 0, s, a);
     else
-        hipLaunchKernelGGL(k_demod<false>, dim3(blocks), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_demod_packed, dim3(blocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

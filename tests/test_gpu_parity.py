@@ -1077,7 +1077,7 @@ def _check_streams_against_oracle(dev, chans, iq_host, wo, ax, zo, nbat, what):
 
 def test_config4_64_streams_x_32_mixed_channels_equal_the_oracle(pkg):
     """BASELINE configs[3] at full width: 64 streams x 32 mixed channels = 2048 rows through mi_demod_process_device (one
-    channel per wave in k_demod<uni>, 2048 waves), three batches, every stream against the oracle: audio, batch flags and
+    channel per wave in k_demod_uni, 2048 waves), three batches, every stream against the oracle: audio, batch flags and
     raw I/Q on the iq channels.  Streams are independent devices (one demod thread per device in the reference,
     rtl_airband.cpp:1044-1078), so each must equal a single-stream oracle run on its own bytes."""
     nstreams, nbat = 64, 3
@@ -1091,7 +1091,7 @@ def test_config4_64_streams_x_32_mixed_channels_equal_the_oracle(pkg):
 
 @pytest.mark.parametrize("uni_rows,nstreams", [(1, 3), (16, 3), (64, 64)])
 def test_lane_packed_k_demod_equals_the_oracle(pkg, uni_rows, nstreams):
-    """Above MI_OPT_UNI_ROWS rows the serial kernel packs several channels into the lanes of a wave (k_demod<false>: its own
+    """Above MI_OPT_UNI_ROWS rows the serial kernel packs several channels into the lanes of a wave (k_demod_packed: its own
     row / lane mapping, no steady blocks, CTCSS per lane).  Forced here on the config-3 plan: 96 rows at 64 lanes per wave and
     at 6 lanes per wave, and the whole configs[3] width (2048 rows) at 32 lanes per wave; every stream equals the oracle."""
     nbat = 3 if nstreams <= 3 else 2
