@@ -233,6 +233,11 @@ int n_fft_for(const mi_demod* h, int nbatches) {
 }
 
 constexpr int kTpMinBatches = 8;  // below this the segments are too few to pay for the extra passes
+// Above this many rows the serial kernel is the faster path by itself: its time is the latency of one row (≈ 20-30 ns per step since
+// round 3) whatever the number of rows, while the wide passes of the time-parallel path grow with them -- 8 / 16 / 32 / 64 streams x 8
+// AM channels, 8-s calls: 1.35 / 1.67 / 2.60 / 4.69 ms time-parallel against 2.4 / 2.5 / 2.5 / 3.9 ms for k_demod, which also leaves
+// stage 1 of the next call more of every SIMD.  MI_OPT_TIME_PARALLEL = 1 still forces the time-parallel path.
+constexpr int kTpAutoMaxRows = 256;
 
 // Defaults of a new handle's tuning switches from the caller's environment (A/B measurements, tests):
 //   MI_AIRBAND_TP=0|1        serial kernel / time-parallel path whenever eligible
@@ -395,7 +400,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     h->last_stage1 = (ca.l64.enabled && h->plan.log2n == 9 && !h->plan.any_afc) ? (ca.l64_jit ? MI_STAGE1_LANE_PLAN : MI_STAGE1_LANE_FULL)
                      : ((ca.prune.enabled && h->plan.log2n == 9 && !h->plan.any_afc) ? MI_STAGE1_EXCHANGE_PRUNED : MI_STAGE1_EXCHANGE_FULL);
     const int env = h->opt_tp;
-    const bool use_tp = h->tp_eligible && env != 0 && (env == 1 || nbatches >= kTpMinBatches);
+    const bool use_tp = h->tp_eligible && env != 0 && (env == 1 || (nbatches >= kTpMinBatches && h->rows <= kTpAutoMaxRows));
     ca.xmax = nullptr;  // (the time-parallel branch points it at its scratch set)
 
     mi::DemodArgs da{};
@@ -791,7 +796,12 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             HIP_TRY(mi::launch_afc(aa, s));
             f0 += nf;
         }
-    } else if (early_input && !h->tp_eligible && !h->first_call && serial_sets_ready(h)) {
+    } else if (early_input && !h->first_call && (!h->tp_eligible || (h->head_off == 0 && (h->d_mag == h->d_mag_set[0] || h->d_mag == h->d_mag_set[1]))) &&
+               serial_sets_ready(h)) {
+        // (a handle whose plan the time-parallel path could take as well -- many rows, or MI_OPT_TIME_PARALLEL = 0 -- pipelines its serial
+        //  calls like any other as long as its planes are where this branch keeps them: never after a time-parallel call)
+        if (h->tp_eligible)
+            h->pset = h->d_mag == h->d_mag_set[1] ? 1 : 0;
         // ---- serial stage 2 with consecutive calls overlapping (MI_OPT_EARLY_INPUT) ----
         // Two plane sets alternate.  Stage 1 of this call fills the body of set p on the front stream while the previous
         // call's k_demod, which reads the other set, still runs on the caller's stream (all that k_demod writes into set p

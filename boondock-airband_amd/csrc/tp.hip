@@ -1345,6 +1345,15 @@ __global__ __launch_bounds__(512) void k_tp_core2(const TpArgs a) {
                                            n_rounds, n_restarts);)
 }
 
+// Register budget of the lane kernels (k_tp_seg / k_tp_fix / k_tp_redo): waves per SIMD they are compiled for, 0 = whatever they take
+#ifndef MI_LANE_EU
+#define MI_LANE_EU 0
+#endif
+#if MI_LANE_EU > 0
+#define MI_LANE_BOUNDS __launch_bounds__(64, MI_LANE_EU)
+#else
+#define MI_LANE_BOUNDS __launch_bounds__(64)
+#endif
 // =====================================================================================================
 // B / D: the segment engine
 // =====================================================================================================
@@ -1957,7 +1966,7 @@ __device__ __forceinline__ void load_core(TpLane& s, const ChanParams& p, const 
     s.level = level_of(p, s.nf, s.recent);
 }
 
-__global__ __launch_bounds__(64) void k_tp_seg(const TpArgs a) {
+__global__ MI_LANE_BOUNDS void k_tp_seg(const TpArgs a) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // blockDim.x = lanes per wave (see launch_tp_seg)
     const int nsc = static_cast<int>(a.seg1 - a.seg0);  // segments of this chunk
     if (gid >= a.nrows * nsc)
@@ -2214,7 +2223,7 @@ __device__ __forceinline__ void rerun_chain(const TpArgs& a, const int r, const 
     }
 }
 
-__global__ __launch_bounds__(64) void k_tp_fix(const TpArgs a) {
+__global__ MI_LANE_BOUNDS void k_tp_fix(const TpArgs a) {
     const int gid = blockIdx.x * 64 + threadIdx.x;
     const int nsc = static_cast<int>(a.seg1 - a.seg0);
     if (gid >= a.nrows * nsc)
@@ -2246,7 +2255,7 @@ __device__ __forceinline__ void redo_segment(const TpArgs& a, const int r, const
 
 // every segment a chain of k_tp_fix passed through, from its true start state, side by side: one segment per wave (a lane that
 // shares its wave with lanes at other points of their segments pays for their paths too), taken from the list the chains left
-__global__ __launch_bounds__(64) void k_tp_redo(const TpArgs a) {
+__global__ MI_LANE_BOUNDS void k_tp_redo(const TpArgs a) {
     const int count = a.redo[0];
     // blockDim.x segments per wave: 1 on plans of few rows (the re-runs are the critical path of the tail), 4 where hundreds of rows
     // leave thousands of them (throughput: the wave pays for every path its lanes take, but four at a time)

@@ -254,7 +254,7 @@ enum {
     /* Tuning switches, all result-neutral (every combination is bit-identical; they exist for measurements and tests).
      * A handle takes its defaults from the caller's environment when it is created (MI_AIRBAND_TP, _PRUNE, _L64, _L64_JIT, _CORE_SPLIT, _CONV=lut|arith,
      * _STEADY, _UNI_ROWS, _TP_CHUNKS, _TP_RATIO, _TP_LPW); the library itself keeps no process-wide state. */
-    MI_OPT_TIME_PARALLEL = 3, /* -1 auto (plain AM plans, calls of >= 8 batches), 0 serial kernel, 1 whenever eligible */
+    MI_OPT_TIME_PARALLEL = 3, /* -1 auto (plain AM plans of up to 256 rows, calls of >= 8 batches), 0 serial kernel, 1 whenever eligible */
     MI_OPT_PRUNE_FFT = 4,     /* 1 (default): at N = 512 evaluate only the FFT nodes the picked bins need */
     MI_OPT_U8_CONVERSION = 5, /* -1 auto, 0 level table in LDS, 1 arithmetic (checked against the table by the plan) */
     MI_OPT_UNI_ROWS = 6,      /* rows (stream x channel) up to which the serial kernel keeps one channel per wave (4096) */

@@ -1213,9 +1213,13 @@ def test_time_parallel_segment_lengths_keep_every_bit(pkg, monkeypatch, seg):
     assert st[0].open_count >= 10
 
 
-def test_time_parallel_many_rows_take_long_segments_and_equal_the_oracle(pkg, monkeypatch):
-    """48 streams x 8 AM channels = 384 rows pick 1024-step segments and full waves in the segment pass by themselves; two
-    overlapping calls through the device entry, every stream against the oracle."""
+@pytest.mark.parametrize("force_tp", [1, -1])
+def test_time_parallel_many_rows_take_long_segments_and_equal_the_oracle(pkg, monkeypatch, force_tp):
+    """48 streams x 8 AM channels = 384 rows.  Forced onto the time-parallel path (MI_OPT_TIME_PARALLEL = 1) they pick 1024-step
+    segments and full waves in the segment pass by themselves; left alone (-1) a plan of more than 256 rows takes the serial
+    kernel -- its time is the latency of one row whatever their number -- and pipelines its calls like a plan the time-parallel path
+    could not take (stage 1 of a call under k_demod of the call before, two plane sets alternating).  Two overlapping calls through
+    the device entry either way, every fifth stream against the oracle."""
     import torch
     monkeypatch.delenv("MI_AIRBAND_TP", raising=False)
     monkeypatch.delenv("MI_AIRBAND_TP_SEGMENT", raising=False)
@@ -1232,6 +1236,9 @@ def test_time_parallel_many_rows_take_long_segments_and_equal_the_oracle(pkg, mo
     iq_host = d_iq.cpu().numpy()
     d = pkg.Demod(dev, chans, nstreams=nstreams, max_batches=max(calls))
     d.set_option(pkg.OPT_EARLY_INPUT, 1)
+    d.set_option(pkg.OPT_TIME_PARALLEL, force_tp)
+    if force_tp < 0:
+        calls = [16, 12, 12]  # (the third call is the second pipelined one: both plane sets have been through)
     outs, done = [], 0
     for k in calls:
         pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
@@ -1241,7 +1248,7 @@ def test_time_parallel_many_rows_take_long_segments_and_equal_the_oracle(pkg, mo
         outs.append((wo, ax))
         done += k
     torch.cuda.synchronize()
-    assert d.last_path() == (1, 0)
+    assert d.last_path()[0] == (1 if force_tp == 1 else 0)
     d.close()
     wo = torch.cat([o[0] for o in outs], dim=2).cpu().numpy()
     ax = torch.cat([o[1] for o in outs], dim=2).cpu().numpy()
