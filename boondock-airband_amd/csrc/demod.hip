@@ -104,6 +104,7 @@ struct Ctx {
     bool split;
     LdsAux* aux;
     unsigned tk_head, d_head;  // tokens / descriptors posted so far
+    unsigned tk_tail_seen, d_tail_seen;  // ... and consumed, as last looked up (the rings are only looked at when these do not leave room)
     unsigned* timeouts;
 };
 
@@ -495,6 +496,16 @@ __device__ __forceinline__ void full_passes16(float& F, float& T, const float B)
     asm volatile("s_nop 1\n" MI_FULL_PASS4 MI_FULL_PASS4 MI_FULL_PASS4 MI_FULL_PASS4 : [F] "+v"(F), [T] "+v"(T) : [B] "v"(B), [K] "v"(K));
 }
 
+// Any chain of the form V[m] = V[m-1] * K + B[m], every product and sum rounded on its own (the AGC averages, the de-emphasis): n
+// passes (rounded up to sixteen) of the same two instructions, lane m = step m, V[-1] = v_in.  Lane 0's shifted source does not
+// exist, so it keeps reading the preset product v_in * K -- the very product its step forms.
+__device__ __forceinline__ float chain_passes(const float v_in, const float B, const float K, const int n) {
+    float V = 0.0f, T = v_in * K;
+    for (int p_ = 0; p_ < n; p_ += 16)
+        asm volatile("s_nop 1\n" MI_FULL_PASS4 MI_FULL_PASS4 MI_FULL_PASS4 MI_FULL_PASS4 : [F] "+v"(V), [T] "+v"(T) : [B] "v"(B), [K] "v"(K));
+    return V;
+}
+
 // One noise-floor period [L, E) (at most 16 steps; lane m = step m) of the pre-filter averages (squelch.cpp:501-514) under the period's
 // cap.  Fin / Cin: full_ / capped_ entering it (wave-uniform).  Two regimes need the recurrence of full_ only -- a third of the
 // instructions of the pair:
@@ -599,7 +610,9 @@ __device__ __forceinline__ void pre_block(const ChanParams& P, float& nf, float&
 }
 
 #ifdef MI_BLOCK_PROF
-#define MI_PROF_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); io.prof[k] += t_ - io.prof_t; io.prof_t = t_; } while (0)
+// (s_memtime is not ordered against the instructions around it and the compiler moves work across it: the scheduling barriers and the
+//  wait for everything in flight pin a mark to its place -- at the price of the overlap they forbid, so the phases are upper bounds)
+#define MI_PROF_MARK(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); io.prof[k] += t_ - io.prof_t; io.prof_t = t_; } while (0)
 #else
 #define MI_PROF_MARK(k) do { } while (0)
 #endif
@@ -650,9 +663,11 @@ __device__ __forceinline__ unsigned aux_peek(const __attribute__((address_space(
 // channel wave: one descriptor, with n tokens (lane m < n holds step arg + m; n == 1 from the sample loop: wave-uniform values)
 __device__ __forceinline__ void aux_post(Ctx& c, const unsigned type, const unsigned n, const unsigned arg, const float re, const float im, const float ax) {
     LdsAux* const x = c.aux;
-    for (unsigned spin = 0;; ++spin) {  // room in both rings (the audio wave is the faster one: normally no wait)
-        const unsigned tt = aux_peek(&x->tk_tail), dt = aux_peek(&x->d_tail);
-        if (c.tk_head + n - tt <= kTokRing && c.d_head + 1u - dt <= kDescRing)
+    for (unsigned spin = 0;; ++spin) {  // room in both rings (the audio wave is the faster one: normally no wait, usually not even a look)
+        if (c.tk_head + n - c.tk_tail_seen <= kTokRing && c.d_head + 1u - c.d_tail_seen <= kDescRing)
+            break;
+        c.tk_tail_seen = aux_peek(&x->tk_tail), c.d_tail_seen = aux_peek(&x->d_tail);
+        if (c.tk_head + n - c.tk_tail_seen <= kTokRing && c.d_head + 1u - c.d_tail_seen <= kDescRing)
             break;
         __builtin_amdgcn_s_sleep(1);
         if (spin > 4u * kPreSpin) {  // (the audio wave is gone: counted, asserted 0 by the tests)
@@ -730,7 +745,11 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
 
 #ifdef MI_BLOCK_PROF
     {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const unsigned long long t_ = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         if (io.blocks)
             io.prof[7] += t_ - io.prof_t;  // since the previous block returned
         io.prof_t = t_;
@@ -890,11 +909,15 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
         if (P.modulation == MI_MOD_AM) {
             const bool upd = xf > level;
             const float bA = xf * 0.005f;
-            float Gp = s.agcavgfast;
-            MI_PASSES(0, kmax, {
-                Gp = shr1(G, Gp);
-                G = upd ? Gp * 0.995f + bA : Gp;
-            })
+            if ((__ballot(!upd) & actmask) == 0ull) {  // every sample above the level: the plain average
+                G = chain_passes(s.agcavgfast, bA, 0.995f, kmax);
+            } else {
+                float Gp = s.agcavgfast;
+                MI_PASSES(0, kmax, {
+                    Gp = shr1(G, Gp);
+                    G = upd ? Gp * 0.995f + bA : Gp;
+                })
+            }
             d = (ax - G) / (G * 1.5f);
             fail = fail || fabsf(d) > 0.8f;  // the clip feeds back into the AGC: the sample loop takes that step
         } else {
@@ -909,18 +932,9 @@ __device__ __forceinline__ int steady_block(Ctx& c, const DemodArgs& a, BlockIo&
                 w = static_cast<float>(static_cast<double>((pr * im - re * pj) / (re * re + im * im + 1.0f)) * M_1_PI);
             }
             const float bN = w * 0.005f;
-            float Gp = s.agcavgfast;
-            MI_PASSES(0, kmax, {
-                Gp = shr1(G, Gp);
-                G = Gp * 0.995f + bN;
-            })
+            G = chain_passes(s.agcavgfast, bN, 0.995f, kmax);
             const float e = (w - G) * P.one_minus_alpha;
-            float D = 0.0f, Dp = s.prev_waveout;
-            MI_PASSES(0, kmax, {
-                Dp = shr1(D, Dp);
-                D = e + Dp * P.alpha;
-            })
-            d = D;
+            d = chain_passes(s.prev_waveout, e, P.alpha, kmax);  // (e + prev * alpha: the product, then the sum)
         }
     }
 
@@ -1156,6 +1170,87 @@ __device__ __forceinline__ void idle_streak(Ctx& c, const DemodArgs& a, BlockIo&
     }
 }
 
+// The open plain AM channel (k_demod_pw, audio on the audio wave): what is left for the channel's wave in OPEN is has_signal() --
+// capped_ >= level, from the ring -- and the low-signal count (squelch.cpp:233-245), and handing (level, wavein[j], wavein[j - 100]) to the
+// audio wave.  As in idle_streak() the state is read from the ring after the last committed step and nothing else of the channel is
+// touched inside the loop (the general block keeps ~150 scalars alive around it and reloads them from memory block after block:
+// ≈ 1 100 cycles between two blocks of ≈ 40 instructions).  Blocks start on a multiple of 16 of sample_count_ -- the first
+// noise-floor update of the block is its first step, so the level cache is cleared there and every step's level is ratio x its
+// own noise floor -- else the general block takes one and aligns.  Same decisions, tokens and state as steady_block<true, SQ_OPEN>.
+__device__ __forceinline__ void open_streak_am(Ctx& c, const DemodArgs& a, BlockIo& bio, uint32_t& gi, const uint32_t ngroups, uint32_t& in_batch, uint32_t& batch,
+                                               bool& batch_open, int& skip, bool& stale, LdsPre* pre, bool& pre_on, const int row) {
+    ChanState& s = c.s;
+    const ChanParams& P = c.p;
+    const int lane = c.lane;
+    const float ratio = (s.recent_open_count >= kFlapOpensThreshold && P.flappy_signal_ratio < P.normal_signal_ratio) ? P.flappy_signal_ratio : P.normal_signal_ratio;
+    const float* __restrict__ xrow = bio.magrow + kAgcExtra;
+    float xn = 0.0f, axn = 0.0f;  // the next block's samples, requested a block ahead
+    uint32_t n_at = 0xffffffffu;
+    for (;;) {
+        int kmax = min(64, static_cast<int>(ngroups - gi) * 4);
+        kmax = min(kmax, kWaveBatch - static_cast<int>(in_batch));  // the batch flag is written at a batch's last step
+        kmax &= ~3;
+        if (kmax < 8 || ((__builtin_amdgcn_readfirstlane(s.sample_count) + 1u) & 15u) != 0u)
+            return;  // the general block (it aligns) or the sample loop
+        const uint32_t i0 = gi * 4;
+        const uint32_t li = min(i0 + static_cast<uint32_t>(lane), bio.n - 1u);
+        float x = xn, ax = axn;
+        if (n_at != i0)
+            x = xrow[li], ax = bio.magrow[li];
+        {
+            const uint32_t ni = i0 + static_cast<uint32_t>(kmax);
+            const uint32_t idx = min(ni + static_cast<uint32_t>(lane), bio.n - 1u);
+            xn = xrow[idx], axn = bio.magrow[idx];
+            n_at = ni;
+        }
+        if (!pre_wait(pre, lane, i0, i0 + static_cast<uint32_t>(kmax))) {
+            pre_on = false;  // (final: see steady_block)
+            if (lane == 0 && a.pre_timeouts)
+                atomicAdd(a.pre_timeouts, 1u);
+            return;
+        }
+        const unsigned at = (i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u);
+        const float C = *(pre_vf32*)&pre->C[at], NFv = *(pre_vf32*)&pre->NF[at];
+        const float level = P.using_manual_level ? P.manual_signal_level : ratio * NFv;
+        asm volatile("" : "+v"(x), "+v"(ax));  // (the samples have arrived: out of the memory counter before the stores below enter it)
+        const unsigned long long actmask = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
+        const unsigned long long ge = __ballot(x >= level);
+        const unsigned long long below = ge & ((2ull << lane) - 1ull);
+        const int lsc = below ? lane - (63 - static_cast<int>(__builtin_clzll(below))) : s.low_signal_count + lane + 1;
+        const unsigned long long failm = __ballot(!(C >= level) || lsc >= kLowSignalAbort) & actmask;
+        const int k = failm ? static_cast<int>(__builtin_ctzll(failm)) : kmax;
+        const int kc = k & ~3;
+        if (kc == 0) {
+            skip = 4;
+            return;
+        }
+        const int last = kc - 1;
+        aux_post(c, AUX_BLOCK, static_cast<unsigned>(kc), i0, level, x, ax);
+        // the state after step `last`
+        const unsigned atl = (i0 + static_cast<uint32_t>(last)) & (kPreRing - 1u);
+        s.noise_floor = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->NF[atl])));
+        s.moving_avg_cap = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->CAP[atl])));
+        s.pre_full = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->F[atl])));
+        s.pre_capped = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->C[atl])));
+        s.squelch_level_cache = P.using_manual_level ? 0.0f : ratio * s.noise_floor;
+        s.low_signal_count = __builtin_amdgcn_readlane(lsc, last);
+        s.sample_count += static_cast<uint32_t>(kc);
+        s.buffer_head = s.buffer_head + kc >= kSquelchRing ? s.buffer_head + kc - kSquelchRing : s.buffer_head + kc;
+        s.buffer_tail = s.buffer_tail + kc >= kSquelchRing ? s.buffer_tail + kc - kSquelchRing : s.buffer_tail + kc;
+        in_batch += static_cast<uint32_t>(kc);
+        if (in_batch == kWaveBatch)
+            MI_END_BATCH();
+        gi += static_cast<uint32_t>(kc / 4);
+        stale = true;  // the group fetched ahead is behind us now
+        if (kc != kmax) {
+            skip = 4;
+            return;
+        }
+        if (gi >= ngroups)
+            return;
+    }
+}
+
 // A run of steady blocks in one state (current_state_ == next_state_ == kSt, or whatever it is for kSt < 0): a block never changes
 // the state, so while blocks commit in full nothing but their lengths has to be worked out between them -- the batch end, the
 // 16-step phase of sample_count_, and in the waiting states the step whose delay_ decides.  Returns with gi at the first group no
@@ -1211,7 +1306,11 @@ __device__ __forceinline__ void steady_streak(Ctx& c, const DemodArgs& a, BlockI
         }
 #ifdef MI_BLOCK_PROF
         {   // split "between blocks": bookkeeping after the return vs loop head + eligibility
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             const unsigned long long t_ = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
             bio.after_ret += t_ - bio.prof_t;
             bio.prof_t = t_;
         }
@@ -1248,6 +1347,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
     c.split = kPre && a.audio_wave && (P.modulation != MI_MOD_AM || TyAmPlain::matches(P));  // (the audio wave decides the same way)
     c.aux = aux;
     c.tk_head = c.d_head = 0;
+    c.tk_tail_seen = c.d_tail_seen = 0;
     c.timeouts = a.pre_timeouts;
     c.ring = a.sq_ring + static_cast<size_t>(row) * kSquelchRing;
     c.cc_fast = c.cc_slow = nullptr;
@@ -1320,6 +1420,10 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
                       if (kPre && st == SQ_CLOSED && pre_on && __builtin_amdgcn_readfirstlane(c.s.closed_sample_count) == kRecentSampleSize &&
                           __builtin_amdgcn_readfirstlane(c.s.recent_open_count) == 0u)
                           idle_streak(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
+                      else if (kPre && st == SQ_OPEN && pre_on && c.split && P.modulation == MI_MOD_AM && !P.using_manual_level &&
+                               __builtin_amdgcn_readfirstlane(c.s.using_post_filter) == 0 &&
+                               ((__builtin_amdgcn_readfirstlane(c.s.sample_count) + 1u) & 15u) == 0u)
+                          open_streak_am(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
                       else if (st == SQ_CLOSED)
                           steady_streak<kPre, SQ_CLOSED>(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
                       else if (st == SQ_OPEN)
@@ -1920,11 +2024,16 @@ __device__ __forceinline__ void audio_wave(const DemodArgs& a, LdsAux* x, const 
                 const float level = *(aux_vf32*)&x->tk_re[at], xs = *(aux_vf32*)&x->tk_im[at], ax = *(aux_vf32*)&x->tk_ax[at];
                 const bool upd = xs > level;
                 const float bA = xs * 0.005f;
-                float G = 0.0f, Gp = agc;
-                MI_PASSES(0, n, {
-                    Gp = shr1(G, Gp);
-                    G = upd ? Gp * 0.995f + bA : Gp;
-                })
+                float G = 0.0f;
+                if (__ballot(lane < n && !upd) == 0ull) {  // every sample above the level: the plain average
+                    G = chain_passes(agc, bA, 0.995f, n);
+                } else {
+                    float Gp = agc;
+                    MI_PASSES(0, n, {
+                        Gp = shr1(G, Gp);
+                        G = upd ? Gp * 0.995f + bA : Gp;
+                    })
+                }
                 const float d = (ax - G) / (G * 1.5f);
                 const unsigned long long clipm = __ballot(lane < n && fabsf(d) > 0.8f);
                 const int k = clipm ? static_cast<int>(__builtin_ctzll(clipm)) : n;  // steps before the first clip
@@ -1999,17 +2108,9 @@ __device__ __forceinline__ void audio_wave(const DemodArgs& a, LdsAux* x, const 
                     w = static_cast<float>(static_cast<double>((prr * im - re * pjj) / (re * re + im * im + 1.0f)) * M_1_PI);
                 }
                 const float bN = w * 0.005f;
-                float G = 0.0f, Gp = agc;
-                MI_PASSES(0, n, {
-                    Gp = shr1(G, Gp);
-                    G = Gp * 0.995f + bN;
-                })
+                const float G = chain_passes(agc, bN, 0.995f, n);
                 const float e = (w - G) * P.one_minus_alpha;
-                float D = 0.0f, Dp = pw;
-                MI_PASSES(0, n, {
-                    Dp = shr1(D, Dp);
-                    D = e + Dp * P.alpha;
-                })
+                const float D = chain_passes(pw, e, P.alpha, n);  // (e + prev * alpha: the product, then the sum)
                 const float d = D;
                 const int last = n - 1;
                 // Squelch::process_audio_sample (squelch.cpp:278-295; the state is OPEN or CLOSING: never CLOSED)
