@@ -272,7 +272,7 @@ def roofline_block(res, kernels, traffic, traffic_src):
     tflops = sps * flop_per_sample / step_s / 1e12
     limited_by = {"k_tp_core": "latency: the serial squelch core chain, one workgroup per channel (dependent VALU issue, not bytes)",
                   "k_channelize": "fp32 VALU / LDS issue of stage 1 (65 flop/B at fft 512: far right of the HBM ridge)",
-                  "k_demod": "VALU issue of one wave per channel (the serial per-channel loop)",
+                  "k_demod": "dependent VALU issue of the waves of one channel (the serial per-channel loop: its longest chain, pre_filter_.full_, where helper waves run)",
                   "k_tp_seg": "lane latency of the segment pass", "k_tp_full": "lane latency of the aggregate pass"}.get(dom.split("#")[0], "launch latency of the tail passes")
     sum_ms = sum(v["ms_per_step"] for v in kernels.values())
     return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -381,7 +381,8 @@ def main():
                        "streams_per_gpu": nstreams, "channels": nch, "fft_size": 1 << res["fft_log"], "capture_seconds_per_step": res["nbat"] / 8.0,
                        "audio_gather_to_rank0": bool(res["gathering"]), "gather": gather_mode if res["gathering"] else None,
                        "gather_overlaps_next_step": bool(res["gathering"]), "partition": "shard.stream_range (stream-major)",
-                       "stage2_path": "time-parallel" if res["path"] == 1 else "serial"},
+                       "stage2_path": ("time-parallel (plain AM rows) + serial kernel (the others), side by side" if "k_demod" in kernels else "time-parallel")
+                       if res["path"] == 1 else "serial"},
             "x_realtime_per_stream": res["value"] / world / nstreams / (SAMPLE_RATE / 1e6),
             "roofline": roofline_block(res, kernels, traffic, traffic_src),
             "kernels": kernels,

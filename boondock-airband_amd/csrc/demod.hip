@@ -24,6 +24,14 @@ enum : int { SQ_CLOSED = 0, SQ_OPENING = 1, SQ_CLOSING = 2, SQ_LOW_SIGNAL_ABORT 
 constexpr int kOpenDelay = 197, kCloseDelay = 197, kLowSignalAbort = 88;  // squelch.cpp:49-51
 constexpr uint32_t kRecentSampleSize = 1000, kFlapOpensThreshold = 3;    // squelch.cpp:62-63
 
+// the handle row (stream * nch + channel) of the idx-th row of this launch
+__device__ __forceinline__ int demod_row(const DemodArgs& a, const int idx) {
+    return a.rows ? a.rows[idx] : idx;
+}
+__device__ __forceinline__ int demod_rows(const DemodArgs& a) {
+    return a.rows ? a.nrows : a.nstreams * a.nch;
+}
+
 // ---- channel types ----
 // A lone wave pays 10 / 24 cycles for a scalar branch (not taken / taken) and 21 / 35 for an exec-masked region (entered / skipped) --
 // as much as 3 to 9 vector instructions (tools/micro/branch_cost.hip) -- and the per-channel loop is full of tests of the channel's
@@ -1330,11 +1338,12 @@ __device__ __forceinline__ void steady_streak(Ctx& c, const DemodArgs& a, BlockI
 template <bool kUni, bool kPre, class T>
 __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsAux* aux) {
     bool pre_on = kPre;  // the pre-filter wave is there and delivering (k_demod_pw)
-    const int rows = a.nstreams * a.nch;
+    const int rows = demod_rows(a);
     constexpr bool uni = kUni;
-    const int row = kUni ? static_cast<int>(blockIdx.x) : static_cast<int>(blockIdx.x) * a.lanes_per_wave + static_cast<int>(threadIdx.x);
-    if ((!kUni && static_cast<int>(threadIdx.x) >= a.lanes_per_wave) || row >= rows)
+    const int ridx = kUni ? static_cast<int>(blockIdx.x) : static_cast<int>(blockIdx.x) * a.lanes_per_wave + static_cast<int>(threadIdx.x);
+    if ((!kUni && static_cast<int>(threadIdx.x) >= a.lanes_per_wave) || ridx >= rows)
         return;
+    const int row = demod_row(a, ridx);
     const int stream = row / a.nch, ch = row - stream * a.nch;
     Ctx c;
     c.uni = uni;
@@ -1369,6 +1378,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
     const float2* zrow = P.needs_raw_iq ? a.cplx + (static_cast<size_t>(stream) * a.n_iq_rows + P.iq_row) * a.plane_stride : nullptr;
     float* __restrict__ wmain = a.wmain + static_cast<size_t>(row) * a.wmain_stride;
     float* __restrict__ carry = a.carry + static_cast<size_t>(row) * kAgcExtra;
+    const float* __restrict__ carry_in = (a.carry_in ? a.carry_in : a.carry) + static_cast<size_t>(row) * kAgcExtra;
     float2* __restrict__ iqo = (a.iq_out && P.has_iq_outputs) ? a.iq_out + static_cast<size_t>(row) * a.iq_out_stride : nullptr;
     const bool has_z = P.needs_raw_iq != 0, has_iqo = iqo != nullptr;
     const uint32_t n = a.nsteps;
@@ -1377,7 +1387,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
 
     // the lookahead of the previous call is the head of this call's emitted audio (output.cpp:948)
     for (int v = 0; v < kAgcExtra; ++v)
-        wmain[v] = carry[v];
+        wmain[v] = carry_in[v];
 
     const bool am = P.modulation == MI_MOD_AM;
     const float ampfactor = P.ampfactor;
@@ -1777,7 +1787,7 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
 template <bool kUni, bool kPre>
 __device__ __forceinline__ void demod_dispatch(const DemodArgs& a, LdsPre* pre, LdsAux* aux) {
     if constexpr (kUni) {
-        const ChanParams& P0 = a.cp[static_cast<int>(blockIdx.x) % a.nch];
+        const ChanParams& P0 = a.cp[demod_row(a, static_cast<int>(blockIdx.x)) % a.nch];
         if (TyAmPlain::matches(P0))
             demod_body<kUni, kPre, TyAmPlain>(a, pre, aux);
         else if (TyNfmLp::matches(P0))
@@ -1823,7 +1833,7 @@ __global__ __launch_bounds__(64, MI_PACKED_EU) void k_demod_packed(const DemodAr
 // the longest dependent chain of the pre-filter pair (two operations per step; the noise floor and, outside the decays, capped_ follow
 // from it in a few operations per period).  Walked here on its own, 64 steps per trip, it sets the pace the pre-filter wave used to.
 __device__ __forceinline__ void full_wave(const DemodArgs& a, LdsPre* pre, const int lane) {
-    const int row = static_cast<int>(blockIdx.x);
+    const int row = demod_row(a, static_cast<int>(blockIdx.x));
     const float* __restrict__ xrow = a.mag + static_cast<size_t>(row) * a.plane_stride + kAgcExtra;
     const uint32_t n = a.nsteps;
     const float k99 = 0.99f, n99 = static_cast<float>(1.0 - static_cast<double>(0.99f));
@@ -1886,7 +1896,7 @@ __device__ __forceinline__ void full_wave(const DemodArgs& a, LdsPre* pre, const
 
 // The pre-filter wave of k_demod_pw: the recurrence of steady_block()'s first phase, block after block over the whole call.
 __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const int lane) {
-    const int row = static_cast<int>(blockIdx.x);
+    const int row = demod_row(a, static_cast<int>(blockIdx.x));
     const ChanParams P = a.cp[row % a.nch];
     const ChanState& s0 = a.st[row];
     const float* __restrict__ xrow = a.mag + static_cast<size_t>(row) * a.plane_stride + kAgcExtra;
@@ -1967,7 +1977,7 @@ __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const 
 // a window is a unit of its own and goes through ctcss_process_lanes() like a step of the sample loop.  The same IEEE operations in
 // the same order on the same operands as there.
 __device__ __forceinline__ void audio_wave(const DemodArgs& a, LdsAux* x, const int lane) {
-    const int row = static_cast<int>(blockIdx.x);
+    const int row = demod_row(a, static_cast<int>(blockIdx.x));
     const int stream = row / a.nch, ch = row - stream * a.nch;
     const ChanParams P = a.cp[ch];
     const bool am = P.modulation == MI_MOD_AM;
@@ -2339,7 +2349,7 @@ __global__ void k_iqgen(const IqGenDerived* __restrict__ cfg, const int16_t* __r
 }  // namespace
 
 hipError_t launch_demod(const DemodArgs& a, hipStream_t s) {
-    const int rows = a.nstreams * a.nch;
+    const int rows = a.rows ? a.nrows : a.nstreams * a.nch;
     if (rows == 0 || a.nsteps == 0)
         return hipSuccess;
     const int blocks = (rows + a.lanes_per_wave - 1) / a.lanes_per_wave;
@@ -2414,19 +2424,20 @@ __global__ void k_afc(const AfcArgs a) {
 }  // namespace
 
 namespace {
-__global__ void k_move_head(float* __restrict__ dst, const float* __restrict__ src, const size_t plane_stride, const int rows) {
+__global__ void k_move_head(float* __restrict__ dst, const float* __restrict__ src, const size_t plane_stride, const int rows, const int* __restrict__ row_list) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= rows * kAgcExtra)
         return;
-    const int r = gid / kAgcExtra, v = gid - r * kAgcExtra;
+    const int ri = gid / kAgcExtra, v = gid - ri * kAgcExtra;
+    const int r = row_list ? row_list[ri] : ri;
     dst[static_cast<size_t>(r) * plane_stride + v] = src[static_cast<size_t>(r) * plane_stride + v];
 }
 }  // namespace
 
-hipError_t launch_move_head(float* dst, const float* src, size_t plane_stride, int rows, hipStream_t s) {
+hipError_t launch_move_head(float* dst, const float* src, size_t plane_stride, int rows, hipStream_t s, const int* row_list) {
     if (rows == 0 || dst == src)
         return hipSuccess;
-    hipLaunchKernelGGL(k_move_head, dim3((rows * kAgcExtra + 255) / 256), dim3(256), 0, s, dst, src, plane_stride, rows);
+    hipLaunchKernelGGL(k_move_head, dim3((rows * kAgcExtra + 255) / 256), dim3(256), 0, s, dst, src, plane_stride, rows, row_list);
     return hipGetLastError();
 }
 

@@ -78,6 +78,8 @@ struct ChannelizeArgs {
 
 struct DemodArgs {
     int nstreams, nch, n_iq_rows, n_ctcss_rows;
+    const int* rows;    // the handle rows (stream * nch + channel) this launch takes, or null: all of them (mixed plans: the rows the
+    int nrows;          // time-parallel path does not take)
     uint32_t nsteps;    // samples per channel in this launch (multiple of WAVE_BATCH)
     uint32_t nbatches;
     float* mag;         // [rows][plane_stride]; index AGC_EXTRA+i is the squelch sample of step i
@@ -88,6 +90,7 @@ struct DemodArgs {
     float* wmain;       // emitted audio, [rows][wmain_stride], nsteps valid
     size_t wmain_stride;
     float* carry;       // [rows][AGC_EXTRA]: lookahead carried between calls
+    const float* carry_in;  // ... the one the previous call left, where that is another buffer (null: `carry`)
     float2* iq_out;     // [rows][iq_out_stride] or null
     size_t iq_out_stride;
     char* axc;          // [rows][axc_stride], nbatches written
@@ -119,7 +122,7 @@ struct AfcArgs {
 };
 hipError_t launch_afc(const AfcArgs& a, hipStream_t s);
 // dst[row][0 .. AGC_EXTRA) = src[row][0 .. AGC_EXTRA) for every plane row (the reference's memmove, rtl_airband.cpp:643-646)
-hipError_t launch_move_head(float* dst, const float* src, size_t plane_stride, int rows, hipStream_t s);
+hipError_t launch_move_head(float* dst, const float* src, size_t plane_stride, int rows, hipStream_t s, const int* row_list = nullptr);  // (row_list: `rows` handle rows)
 
 // ---- time-parallel stage 2 (tp.hip) ----
 // Steps per segment (TpArgs::L): 512 .. 4096, a power of two, chosen per handle from its row count.  One stream x 8 channels

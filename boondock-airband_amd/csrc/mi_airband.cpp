@@ -88,7 +88,7 @@ struct mi_demod {
     // reads (mi_demod_kernel_time_prev, age 3) -- the tail of a call ends about one call after its core chain, and with only two
     // queued the front of the next call started late every few calls
     static constexpr int kSets = 4;
-    hipEvent_t ev[kSets][4] = {};  // per call: 0 begin, 1 stage 1 done, 2 call done, 3 serial k_demod begins (pipelined serial calls)
+    hipEvent_t ev[kSets][5] = {};  // per call: 0 begin, 1 stage 1 done, 2 call done, 3 serial k_demod begins (pipelined serial calls, mixed plans), 4 ... ends (mixed plans)
     static constexpr int kMaxChunks = 64, kEvPerChunk = 13, kSegStreams = 1;
     std::vector<hipEvent_t> chunk_ev[kSets];  // per chunk: stage1 begin/end, full end, core begin/end, seg begin/end, scan0/fix0/finish ends, rest begin
     hipStream_t aux_stream = nullptr;    // carries the serial core chain of the time-parallel path
@@ -199,8 +199,18 @@ struct mi_demod {
     bool failed = false;  // a call advanced the DSP state and then could not deliver its results: every further call is refused
     hipStream_t copy_stream = nullptr;  // uploads of submitted calls
     hipStream_t down_stream = nullptr;  // their downloads
-    // time-parallel stage 2 (tp.hip): only when every channel is a plain AM channel
+    // time-parallel stage 2 (tp.hip): the plain AM channels of the plan.  A mixed plan (tp_mixed) sends those rows down the time-parallel
+    // path and the others through the serial kernel in the same call (MI_OPT_MIXED_PLAN), on a stream of its own beside the chain.
     bool tp_eligible = false;
+    bool tp_mixed = false;
+    bool opt_mixed = true;
+    int tp_rows = 0, ser_rows = 0;       // rows of either kind (tp_rows + ser_rows == rows)
+    int* d_srows = nullptr;              // the serial kernel's rows of a mixed plan (d_rows: the time-parallel path's)
+    hipStream_t ser_stream = nullptr;    // ... and its stream
+    hipEvent_t ev_cplx_free[2] = {};     // the serial kernel of a mixed call has read complex plane set p
+    bool cplx_busy[2] = {};
+    bool ser_head_next = false;          // the serial kernel of the last (mixed) call left its rows' carried samples in the next plane set
+    bool set_mixed[kSets] = {};
     int last_path = 0;  // 0 = serial kernel, 1 = time-parallel
     int* d_rows = nullptr;
     unsigned* d_xmax[kSets] = {};
@@ -287,6 +297,8 @@ void tuning_from_env(mi_demod* h) {
         h->opt_core_guess = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_PRE_WAVE"))
         h->opt_pre_wave = std::atoi(e) < 0 ? -1 : (std::atoi(e) != 0 ? 1 : 0);
+    if (const char* e = get("MI_AIRBAND_MIXED"))
+        h->opt_mixed = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_AUDIO_WAVE"))
         h->opt_audio_wave = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_SPEC_HEAD"))
@@ -400,12 +412,16 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     h->last_stage1 = (ca.l64.enabled && h->plan.log2n == 9 && !h->plan.any_afc) ? (ca.l64_jit ? MI_STAGE1_LANE_PLAN : MI_STAGE1_LANE_FULL)
                      : ((ca.prune.enabled && h->plan.log2n == 9 && !h->plan.any_afc) ? MI_STAGE1_EXCHANGE_PRUNED : MI_STAGE1_EXCHANGE_FULL);
     const int env = h->opt_tp;
-    const bool use_tp = h->tp_eligible && env != 0 && (env == 1 || (nbatches >= kTpMinBatches && h->rows <= kTpAutoMaxRows));
+    const bool use_tp = h->tp_eligible && env != 0 && (!h->tp_mixed || (h->opt_mixed && serial_sets_ready(h))) &&
+                        (env == 1 || (nbatches >= kTpMinBatches && h->tp_rows <= kTpAutoMaxRows));
     ca.xmax = nullptr;  // (the time-parallel branch points it at its scratch set)
 
     mi::DemodArgs da{};
     da.nstreams = h->nstreams;
     da.nch = h->nch;
+    da.rows = nullptr;
+    da.nrows = h->rows;
+    da.carry_in = nullptr;
     da.n_iq_rows = h->plan.n_iq_rows;
     da.n_ctcss_rows = h->plan.n_ctcss_rows;
     da.nsteps = static_cast<uint32_t>(nbatches) * mi::kWaveBatch;
@@ -500,8 +516,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         // (isolated calls, round 2: with the chain on three waves an isolated call is a sum of fixed latencies -- stage 1, aggregates,
         // chain, segment pass, scan, fix, finish -- and every chunk adds the last four once more: 2 chunks, the second twice the
         // first, 3.7 instead of 4.1 ms per 64-s call and 2.6 instead of 3.3 per 16-s call; with many rows 2, 3 and 4 are level)
-        int want = overlap ? (h->rows <= 64 ? 1 : 2) : (h->rows <= 64 ? 2 : 3);
-        double ratio = overlap ? 1.0 : (h->rows <= 64 ? 2.0 : 1.5);
+        int want = overlap ? (h->tp_rows <= 64 ? 1 : 2) : (h->tp_rows <= 64 ? 2 : 3);
+        double ratio = overlap ? 1.0 : (h->tp_rows <= 64 ? 2.0 : 1.5);
         if (h->opt_tp_chunks > 0)
             want = h->opt_tp_chunks;
         if (h->opt_tp_ratio > 0)
@@ -536,7 +552,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         evc = h->ev[q];
         mi::TpArgs ta{};
         ta.rows = h->d_rows;
-        ta.nrows = h->rows;
+        ta.nrows = h->tp_rows;
         ta.nch = h->nch;
         ta.nsteps = n;
         ta.nbatches = da.nbatches;
@@ -606,6 +622,12 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             return c;
         };
         const bool first_call = h->first_call;
+        // A mixed plan: stage 1 leaves the raw bins of this call in complex plane set p, the serial kernel reads them there and leaves
+        // its carried head in the other set for the next call (as the pipelined serial calls do).
+        const int zp = (h->d_cplx && h->d_cplx == h->d_cplx_set[1]) ? 1 : 0, znp = zp ^ 1;
+        if (h->tp_mixed) {
+            ca.cplx = h->d_cplx_set[zp];
+        }
         // The wide passes of a call (stage 1, aggregates, segment pass: thousands of waves that hold most of a SIMD's registers for a
         // millisecond) run beside the latency-bound kernels of its neighbours: the core chains, and the tail (scan / fix / redo /
         // settle / finish: a handful of lanes, 280-430 VGPRs a wave), which then wait for a wide wave to retire before they can
@@ -614,7 +636,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         // with the NULL stream): the twins are created at the handle's first time-parallel call and used by every call whose stream
         // is not the NULL stream.
         if (h->masked_state == 0) {
-            const int want = h->opt_reserve_cus >= 0 ? h->opt_reserve_cus : (h->rows <= 64 ? 32 : 0);
+            const int want = h->opt_reserve_cus >= 0 ? h->opt_reserve_cus : (h->tp_rows <= 64 ? 32 : 0);
             h->masked_state = 2;
             hipDeviceProp_t prop{};
             if (want > 0 && hipGetDeviceProperties(&prop, h->gpu) == hipSuccess && prop.multiProcessorCount >= want + 32) {
@@ -673,8 +695,14 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             if (h->set_seq[qn] && h->set_path[qn] == 1 && h->tp_chunks[qn] > 0)
                 HIP_TRY(hipStreamWaitEvent(fs, h->chunk_ev[qn][static_cast<size_t>(h->tp_chunks[qn] - 1) * mi_demod::kEvPerChunk + 6], 0));
         }
-        // the carried samples of the previous call (wherever they are) become the head of this call's planes
-        HIP_TRY(mi::launch_move_head(planes, h->d_mag + h->head_off, h->plane_stride, h->rows, fs));
+        if (h->tp_mixed && h->cplx_busy[zp])  // (the serial kernel of the call before the previous one read this complex plane set)
+            HIP_TRY(hipStreamWaitEvent(fs, h->ev_cplx_free[zp], 0));
+        // the carried samples of the previous call (wherever they are) become the head of this call's planes -- of a mixed plan the
+        // time-parallel rows' only where the serial kernel of the previous call has put its own rows' there itself
+        if (h->tp_mixed && h->ser_head_next && planes == h->d_mag_set[(h->cur + 1) % mi_demod::kSets])
+            HIP_TRY(mi::launch_move_head(planes, h->d_mag + h->head_off, h->plane_stride, h->tp_rows, fs, h->d_rows));
+        else
+            HIP_TRY(mi::launch_move_head(planes, h->d_mag + h->head_off, h->plane_stride, h->rows, fs));
         HIP_TRY(hipMemsetAsync(h->d_xmax[q], 0, static_cast<size_t>(h->rows) * sizeof(unsigned), fs));
         // Stage 1 + aggregates of every chunk first: nothing else feeds them (when calls overlap, k_tp_full warms its first
         // lanes up on the previous call's planes, so not even the chain state of that call).
@@ -745,6 +773,41 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
             HIP_TRY(hipEventRecord(ev(i, 10), s));
             hipEvent_t marks[mi::TP_REST_MARKS] = {ev(i, 7), ev(i, 8), ev(i, 9)};
             HIP_TRY(mi::launch_tp_rest(c, s, marks));
+        }
+        h->set_mixed[q] = false;
+        h->ser_head_next = false;
+        if (h->tp_mixed && h->ser_rows > 0) {
+            // ---- the rows the time-parallel path does not take: k_demod on its own stream, beside the chain ----
+            // It needs stage 1 of the whole call (the last chunk's end on the front stream), the serial kernel of the previous call
+            // (same stream) and, where calls do not overlap, the caller's stream order.
+            hipStream_t zs = h->ser_stream;
+            HIP_TRY(hipStreamWaitEvent(zs, ev(C - 1, 1), 0));
+            if (!overlap)
+                HIP_TRY(hipStreamWaitEvent(zs, h->ev_entry, 0));
+            if (!seg_early)
+                HIP_TRY(hipStreamWaitEvent(zs, h->ev_head, 0));  // (it writes the audio buffer the previous call wrote)
+            mi::DemodArgs dm = da;
+            dm.rows = h->d_srows;
+            dm.nrows = h->ser_rows;
+            dm.mag = planes;
+            dm.cplx = h->d_cplx_set[zp];
+            dm.mag_head = h->d_mag_set[(q + 1) % mi_demod::kSets];  // (free: the call that used it last is four calls back)
+            dm.cplx_head = h->d_cplx_set[znp];
+            dm.carry = h->d_carry_set[q];
+            dm.carry_in = h->d_carry;
+            dm.lanes_per_wave = std::min(64, std::max(1, (h->ser_rows + h->opt_uni_rows - 1) / h->opt_uni_rows));
+            dm.pre_wave = (h->opt_pre_wave < 0 ? h->ser_rows <= 256 : h->opt_pre_wave != 0) ? 1 : 0;
+            HIP_TRY(hipEventRecord(evc[3], zs));
+            HIP_TRY(mi::launch_demod(dm, zs));
+            HIP_TRY(hipEventRecord(evc[4], zs));
+            HIP_TRY(hipEventRecord(h->ev_cplx_free[zp], zs));
+            h->cplx_busy[zp] = true;
+            HIP_TRY(hipStreamWaitEvent(s, evc[4], 0));
+            h->d_cplx = h->d_cplx_set[znp];
+            h->d_cplx_last = h->d_cplx_set[zp];
+            h->pset = znp;
+            h->set_mixed[q] = true;
+            h->ser_head_next = true;
         }
         h->tp_chunks[q] = C;
         h->cur = q;
@@ -853,6 +916,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         HIP_TRY(mi::launch_demod(da, s));
     }
     h->last_path = use_tp ? 1 : 0;
+    if (!use_tp)
+        h->ser_head_next = false;
     HIP_TRY(hipEventRecord(evc[2], s));
     h->set_seq[h->cur] = ++h->call_seq;
     h->set_path[h->cur] = pipelined_serial ? 2 : h->last_path;
@@ -882,7 +947,7 @@ void mi_demod_destroy(mi_demod* h) {
     (void)hipDeviceSynchronize();  // calls may still be in flight on the handle's own streams
     void* ptrs[] = {h->d_window, h->d_tw, h->d_prune_t1, h->d_prune_t2, h->d_prune_rank, h->d_l64_chan, h->d_l64_chan_full, h->d_l64_tickets, h->d_levels,      h->d_sin,     h->d_cos,   h->d_cp, h->d_state, h->d_cplx_set[0], h->d_cplx_set[1], h->d_carry_set[0], h->d_carry_set[1], h->d_carry_set[2], h->d_carry_set[3],
                     h->d_ring,   h->d_ctcss_coeff, h->d_ctcss_q, h->d_stats, h->d_pre_timeouts,
-                    h->d_rows,   h->d_tstart, h->d_need, h->d_redo, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_fullbound, h->d_afc_spec};
+                    h->d_rows,   h->d_srows, h->d_tstart, h->d_need, h->d_redo, h->d_fin, h->d_diag, h->d_core_carry, h->d_full0, h->d_fullbound, h->d_afc_spec};
     for (void* p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -924,6 +989,11 @@ void mi_demod_destroy(mi_demod* h) {
         (void)hipEventDestroy(h->ev_head);
     if (h->aux_stream)
         (void)hipStreamDestroy(h->aux_stream);
+    if (h->ser_stream)
+        (void)hipStreamDestroy(h->ser_stream);
+    for (hipEvent_t e : h->ev_cplx_free)
+        if (e)
+            (void)hipEventDestroy(e);
     if (h->front_stream_m)
         (void)hipStreamDestroy(h->front_stream_m);
     for (hipStream_t ss : h->seg_stream_m)
@@ -1055,13 +1125,21 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
     if (h->d_cplx)
         TRY_OR_BAIL(hipMemset(h->d_cplx, 0, static_cast<size_t>(nstreams) * p.n_iq_rows * h->plane_stride * 8));
     TRY_OR_BAIL(hipMemset(h->d_stats, 0, rows * sizeof(mi_channel_stats)));
-    h->tp_eligible = true;
-    for (const mi::ChanParams& c : p.cp)
-        if (c.modulation != MI_MOD_AM || c.needs_raw_iq || c.ctcss_enabled || c.notch_enabled || c.afc != 0)
-            h->tp_eligible = false;
+    // which channels the time-parallel path can take: plain AM (no raw I/Q, CTCSS, notch); none where AFC moves the bins batch by batch
+    std::vector<char> tp_ch(static_cast<size_t>(nch), 0);
+    int tp_nch = 0;
+    for (int c = 0; c < nch; ++c) {
+        const mi::ChanParams& cp = p.cp[static_cast<size_t>(c)];
+        tp_ch[static_cast<size_t>(c)] = !p.any_afc && cp.modulation == MI_MOD_AM && !cp.needs_raw_iq && !cp.ctcss_enabled && !cp.notch_enabled && cp.afc == 0;
+        tp_nch += tp_ch[static_cast<size_t>(c)] ? 1 : 0;
+    }
+    h->tp_eligible = tp_nch > 0;
+    h->tp_mixed = tp_nch > 0 && tp_nch < nch;
+    h->tp_rows = nstreams * tp_nch;
+    h->ser_rows = h->rows - h->tp_rows;
     h->core_split_ok = h->tp_eligible;
-    for (const mi::ChanParams& c : p.cp)
-        if (c.using_manual_level || !(c.cap_factor >= 1.0f))
+    for (int c = 0; c < nch; ++c)
+        if (tp_ch[static_cast<size_t>(c)] && (p.cp[static_cast<size_t>(c)].using_manual_level || !(p.cp[static_cast<size_t>(c)].cap_factor >= 1.0f)))
             h->core_split_ok = false;  // (the chain wave's operand assumes cap >= noise floor in a burst)
     if (p.any_afc)
         TRY_OR_BAIL(dalloc(&h->d_afc_spec, static_cast<size_t>(nstreams) * p.fft_size));
@@ -1070,15 +1148,29 @@ int mi_demod_create(const mi_device_cfg* dev, const mi_channel_cfg* chans, int n
         // segment length of the time-parallel path: short segments where rows are few (the parallelism has to come from time),
         // long ones where they are many (each lane pays TP_W steps of warm-up whatever its segment's length)
         if (h->opt_tp_L == 0)
-            h->tp_L = h->rows <= 32 ? 512u : 1024u;  // (2048 beyond 128 rows until the segment pass ran full waves: DESIGN 6)
+            h->tp_L = h->tp_rows <= 32 ? 512u : 1024u;  // (2048 beyond 128 rows until the segment pass ran full waves: DESIGN 6)
         else
             h->tp_L = static_cast<uint32_t>(h->opt_tp_L);
         h->tp_max_seg = (max_steps + h->tp_L - 1) / h->tp_L;
-        std::vector<int> ident(rows);
+        std::vector<int> tp_list, ser_list;  // handle rows (stream * nch + channel) of either kind, in row order
         for (size_t i = 0; i < rows; ++i)
-            ident[i] = static_cast<int>(i);
+            (tp_ch[i % static_cast<size_t>(nch)] ? tp_list : ser_list).push_back(static_cast<int>(i));
         TRY_OR_BAIL(dalloc(&h->d_rows, rows));
-        TRY_OR_BAIL(hipMemcpy(h->d_rows, ident.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+        TRY_OR_BAIL(hipMemcpy(h->d_rows, tp_list.data(), tp_list.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (!ser_list.empty()) {
+            TRY_OR_BAIL(dalloc(&h->d_srows, ser_list.size()));
+            TRY_OR_BAIL(hipMemcpy(h->d_srows, ser_list.data(), ser_list.size() * sizeof(int), hipMemcpyHostToDevice));
+            {
+                // HIP multiplexes its streams onto a few hardware queues and two streams that share one run their kernels one after the
+                // other: on a stream of the default class the serial kernel (a millisecond and more) took turns with stage 1 of the next
+                // call.  The lowest stream priority is a queue class of its own.
+                int lo_prio = 0, hi_prio = 0;
+                TRY_OR_BAIL(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+                TRY_OR_BAIL(hipStreamCreateWithPriority(&h->ser_stream, hipStreamNonBlocking, lo_prio));
+            }
+            for (hipEvent_t& e : h->ev_cplx_free)
+                TRY_OR_BAIL(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
         for (int q = 1; q < mi_demod::kSets; ++q) {
             TRY_OR_BAIL(dalloc(&h->d_mag_set[q], rows * h->plane_stride));
             TRY_OR_BAIL(hipMemset(h->d_mag_set[q], 0, rows * h->plane_stride * 4));
@@ -1644,6 +1736,7 @@ int mi_demod_set_state(mi_demod* h, const void* buf, size_t len) {
     HIP_TRY(push(h->d_ctcss_q, static_cast<size_t>(h->nstreams) * h->plan.n_ctcss_rows * 4 * mi::kMaxTones * 4));
     HIP_TRY(hipMemcpy2D(h->d_mag, h->plane_stride * 4, o, mi::kAgcExtra * 4, mi::kAgcExtra * 4, rows, hipMemcpyHostToDevice));
     h->head_off = 0;
+    h->ser_head_next = false;
     h->chain_live = false;  // the chain state of the time-parallel path is re-seeded from the restored ChanState
     o += rows * mi::kAgcExtra * 4;
     const size_t zrows = static_cast<size_t>(h->nstreams) * h->plan.n_iq_rows;
@@ -1664,7 +1757,7 @@ int mi_demod_last_path(mi_demod* h, int* time_parallel, int* unverified_rows) {
     if (unverified_rows) {
         *unverified_rows = 0;
         if (h->last_path == 1) {
-            std::vector<mi::TpFinal> f(static_cast<size_t>(h->rows));
+            std::vector<mi::TpFinal> f(static_cast<size_t>(h->tp_rows));
             HIP_TRY(hipMemcpy(f.data(), h->d_fin, f.size() * sizeof(mi::TpFinal), hipMemcpyDeviceToHost));
             for (const mi::TpFinal& x : f)
                 *unverified_rows += x.all_ok ? 0 : 1;
@@ -1690,7 +1783,7 @@ int mi_demod_last_stage1(mi_demod* h, int* kind) {
 }
 
 int mi_demod_tp_debug(mi_demod* h, int row, float* core4, int max_entries, int* diag4, int* nseg) {
-    if (!h || row < 0 || row >= h->rows || !h->tp_eligible || h->last_path != 1)
+    if (!h || row < 0 || row >= h->tp_rows || !h->tp_eligible || h->last_path != 1)
         return fail(MI_ERR_INVALID, "the last call did not take the time-parallel path");
     HIP_TRY(hipSetDevice(h->gpu));
     HIP_TRY(hipDeviceSynchronize());
@@ -1702,7 +1795,7 @@ int mi_demod_tp_debug(mi_demod* h, int row, float* core4, int max_entries, int* 
     }
     if (diag4) {  // [0..3] scan rounds, [4..7] core-chain blocks: in accepted runs, single O(1), stepped, failed hypotheses
         HIP_TRY(hipMemcpy(diag4, h->d_diag + static_cast<size_t>(row) * 4, 4 * sizeof(int), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(diag4 + 4, h->d_diag + static_cast<size_t>(h->rows) * 4 + static_cast<size_t>(row) * 4, 4 * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(diag4 + 4, h->d_diag + static_cast<size_t>(h->tp_rows) * 4 + static_cast<size_t>(row) * 4, 4 * sizeof(int), hipMemcpyDeviceToHost));
     }
     return MI_OK;
 }
@@ -1751,6 +1844,16 @@ static int kernel_time_of(mi_demod* h, int age, int index, const char** name, fl
         // 5 seg begin, 12 seg end, 6 all segment launches of the chunk done (segment stream), 10 scan#0 begin, 7 scan#0 end, 8 fix#0 + redo#0 end, 9 finish end (caller's stream), 11 k_tp_full begin
         static const char* const names[] = {"k_channelize", "k_tp_full", "k_tp_core", "k_tp_seg", "k_tp_scan#0", "k_tp_fix#0", "k_tp_rest"};
         static const int from[] = {0, 11, 3, 5, 10, 7, 8}, to[] = {1, 2, 4, 12, 7, 8, 9};
+        if (index == 7 && h->set_mixed[q]) {  // a mixed plan: the serial kernel of the other rows, on its own stream
+            HIP_TRY(hipEventElapsedTime(&t, evq[3], evq[4]));
+            if (name)
+                *name = "k_demod";
+            if (ms_total)
+                *ms_total = t;
+            if (launches)
+                *launches = 1;
+            return MI_OK;
+        }
         if (index > 6)
             return fail(MI_ERR_INVALID, "kernel index out of range");
         nm = names[index];
@@ -1876,6 +1979,9 @@ int mi_demod_set_option(mi_demod* h, int option, int value) {
             return MI_OK;
         case MI_OPT_AUDIO_WAVE:
             h->opt_audio_wave = value != 0;
+            return MI_OK;
+        case MI_OPT_MIXED_PLAN:
+            h->opt_mixed = value != 0;
             return MI_OK;
         default:
             return fail(MI_ERR_INVALID, "unknown option");

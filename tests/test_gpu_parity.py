@@ -899,6 +899,76 @@ def test_audio_wave_same_bits_and_state(pkg, seed, per_call):
     assert_same(wo[0], owo, "audio vs oracle")
 
 
+@pytest.mark.parametrize("mixed", [1, 0])
+def test_mixed_plan_rows_take_both_paths(pkg, monkeypatch, mixed):
+    """MI_OPT_MIXED_PLAN: in a plan that holds plain AM channels beside others (the 24-channel zoo: AM with a manual level and with an
+    SNR threshold, low-pass, notch, raw I/Q, NFM, CTCSS) a call of 8 batches and more sends the plain AM rows down the time-parallel
+    path and the rest through the serial kernel on a stream of its own -- the raw bins in alternating complex plane sets, the serial
+    rows' carried samples left in the next call's planes, both halves sharing one audio lookahead buffer per call.  Two streams,
+    calls of 8 / 12 / 8 batches overlapping on alternating audio buffers, then a 2-batch call (serial for every row) and a last
+    mixed one after it, then a checkpoint taken in the middle is restored into a fresh handle: audio, flags and raw I/Q equal the
+    oracle's throughout, with the option on and off."""
+    import torch
+    monkeypatch.delenv("MI_AIRBAND_TP", raising=False)
+    centre, chans = _channel_zoo(pkg)
+    dev = pkg.device_cfg(centerfreq=centre, fft_size_log=9)
+    calls = [8, 12, 8, 2, 10]
+    nbat = sum(calls)
+    nstreams = 2
+    iqs = [_zoo_capture(pkg, dev, centre, chans, nbat, 1234 + st) for st in range(nstreams)]
+    oracle = [oracle_run(dev, chans, iq, nbat, want_iq=True) for iq in iqs]
+    pad = (max(iq.size for iq in iqs) + 255) // 256 * 256
+    d_iq = torch.zeros((nstreams, pad), dtype=torch.uint8, device="cuda")
+    for st, iq in enumerate(iqs):
+        d_iq[st, :iq.size] = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+
+    def run(d, first_call, ncalls, done):
+        outs, flags, zs = [], [], []
+        for k in calls[first_call:first_call + ncalls]:
+            pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+            wo = torch.empty((nstreams, len(chans), k * WAVE_BATCH), dtype=torch.float32, device="cuda")
+            ax = torch.empty((nstreams, len(chans), k), dtype=torch.uint8, device="cuda")
+            zo = torch.zeros((nstreams, len(chans), k * WAVE_BATCH, 2), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            d.process_device(d_iq.data_ptr() + pos, pad, k, wo.data_ptr(), ax.data_ptr(), d_iq_out_ptr=zo.data_ptr(), hip_stream=side.cuda_stream)
+            outs.append(wo), flags.append(ax), zs.append(zo)
+            done += k
+        torch.cuda.synchronize()
+        return outs, flags, zs, done
+
+    d = pkg.Demod(dev, chans, nstreams=nstreams, max_batches=max(calls))
+    d.set_option(pkg.OPT_EARLY_INPUT, 1)
+    d.set_option(pkg.OPT_MIXED_PLAN, mixed)
+    o1, f1, z1, done = run(d, 0, 3, 0)
+    assert d.last_path()[0] == mixed
+    state = d.get_state().copy()
+    o2, f2, z2, done2 = run(d, 3, 2, done)
+    assert d.last_path() == (mixed, 0)
+    assert d.pre_wave_timeouts() == 0
+    d.close()
+    # the same two calls again from the checkpoint, in a fresh handle
+    d = pkg.Demod(dev, chans, nstreams=nstreams, max_batches=max(calls))
+    d.set_option(pkg.OPT_EARLY_INPUT, 1)
+    d.set_option(pkg.OPT_MIXED_PLAN, mixed)
+    d.set_state(state)
+    o3, f3, z3, _ = run(d, 3, 2, done)
+    d.close()
+    for name, outs, flags, zs in (("straight", o1 + o2, f1 + f2, z1 + z2), ("restored", o1 + o3, f1 + f3, z1 + z3)):
+        wo = torch.cat(outs, dim=2).cpu().numpy()
+        ax = torch.cat(flags, dim=2).cpu().numpy()
+        zo = torch.cat(zs, dim=2).cpu().numpy()
+        for st in range(nstreams):
+            nb, owo, oaxc, oiq = oracle[st]
+            assert nb == nbat
+            assert_same(ax[st], oaxc, f"flags, stream {st}, {name}")
+            assert_same(wo[st], owo, f"audio, stream {st}, {name}")
+            for c, ch in enumerate(chans):
+                if ch.has_iq_outputs:
+                    assert_same(zo[st, c].reshape(-1), oiq[c], f"raw I/Q, stream {st}, channel {c}, {name}")
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_steady_blocks_random_plans(pkg, seed):
     """Random channel plans and captures (modulation, low-pass, notch, CTCSS, manual / SNR squelch thresholds down to 0 dB,
