@@ -248,6 +248,11 @@ constexpr int kTpMinBatches = 8;  // below this the segments are too few to pay 
 // AM channels, 8-s calls: 1.35 / 1.67 / 2.60 / 4.69 ms time-parallel against 2.4 / 2.5 / 2.5 / 3.9 ms for k_demod, which also leaves
 // stage 1 of the next call more of every SIMD.  MI_OPT_TIME_PARALLEL = 1 still forces the time-parallel path.
 constexpr int kTpAutoMaxRows = 256;
+// A mixed plan's call is as long as the longer of its two halves, and the time-parallel half has a fixed latency of a millisecond and
+// more whatever the call's length (segment pass, scan, fix ...), while the serial kernel takes 0.3 ms per second of signal for every
+// row: the split pays from about six seconds per call on (8 streams x 32 mixed channels, 2 / 4 / 8 s per call: 1.36 / 1.83 / 2.24 ms
+// split against 0.70 / 1.41 / 2.58 whole; 1 stream x 32 at fft 2048, 8 s: 1.85 against 2.51).
+constexpr int kMixedMinBatches = 64;
 
 // Defaults of a new handle's tuning switches from the caller's environment (A/B measurements, tests):
 //   MI_AIRBAND_TP=0|1        serial kernel / time-parallel path whenever eligible
@@ -413,7 +418,7 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
                      : ((ca.prune.enabled && h->plan.log2n == 9 && !h->plan.any_afc) ? MI_STAGE1_EXCHANGE_PRUNED : MI_STAGE1_EXCHANGE_FULL);
     const int env = h->opt_tp;
     const bool use_tp = h->tp_eligible && env != 0 && (!h->tp_mixed || (h->opt_mixed && serial_sets_ready(h))) &&
-                        (env == 1 || (nbatches >= kTpMinBatches && h->tp_rows <= kTpAutoMaxRows));
+                        (env == 1 || (nbatches >= (h->tp_mixed ? kMixedMinBatches : kTpMinBatches) && h->tp_rows <= kTpAutoMaxRows));
     ca.xmax = nullptr;  // (the time-parallel branch points it at its scratch set)
 
     mi::DemodArgs da{};

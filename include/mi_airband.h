@@ -282,7 +282,8 @@ enum {
                                * axcindicate and the audio / raw-I/Q stores -- from the channel's own wave (demod.hip, audio_wave) */
     MI_OPT_MIXED_PLAN = 17,   /* 1 (default): a plan that holds plain AM channels beside others (NFM, CTCSS, notch, low-pass, raw I/Q) sends the
                                * plain AM rows down the time-parallel path and the rest through the serial kernel, side by side in the same
-                               * call (calls of >= 8 batches); 0: such a plan takes the serial kernel for every row */
+                               * call (by itself in calls of >= 64 batches -- the time-parallel half has a fixed latency --, in any call under
+                               * MI_OPT_TIME_PARALLEL = 1); 0: such a plan takes the serial kernel for every row */
     MI_OPT_LANE_FFT_JIT = 11  /* 1 (default): that kernel is compiled for the plan's own FFT nodes by hipRTC on first use (the code object is
                                * cached per (device, hop, masks) for the life of the process); 0, or hipRTC missing: the prebuilt full graph */
 };

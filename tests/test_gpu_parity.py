@@ -927,6 +927,8 @@ def test_mixed_plan_rows_take_both_paths(pkg, monkeypatch, mixed):
     def run(d, first_call, ncalls, done):
         outs, flags, zs = [], [], []
         for k in calls[first_call:first_call + ncalls]:
+            # (by itself a mixed plan splits from 64 batches per call on: forced here for the long calls, off for the short one)
+            d.set_option(pkg.OPT_TIME_PARALLEL, 1 if k >= 8 else 0)
             pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
             wo = torch.empty((nstreams, len(chans), k * WAVE_BATCH), dtype=torch.float32, device="cuda")
             ax = torch.empty((nstreams, len(chans), k), dtype=torch.uint8, device="cuda")
