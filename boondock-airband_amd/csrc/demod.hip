@@ -1114,22 +1114,43 @@ __device__ __forceinline__ void idle_streak(Ctx& c, const DemodArgs& a, BlockIo&
     ChanState& s = c.s;
     const ChanParams& P = c.p;
     const int lane = c.lane;
+    // Inside the loop only what the next block needs is kept up (position, batch, the squelch ring's head); the rest of the state --
+    // the averages, the noise floor, the level cache, sample_count_ -- is read from the ring once, when the run ends.
+    uint32_t end = 0;           // steps [.., end) have been committed by this run (0: none)
+    int head = s.buffer_head;   // (buffer_tail_ follows at the same distance: advanced by the same count at the end)
+    const uint32_t i_first = gi * 4;
+    const int phase0 = static_cast<int>((__builtin_amdgcn_readfirstlane(s.sample_count) + 1u) & 15u);
     for (;;) {
         int kmax = min(64, static_cast<int>(ngroups - gi) * 4);
         kmax = min(kmax, kWaveBatch - static_cast<int>(in_batch));  // the batch flag is written at a batch's last step
-        const int phase = static_cast<int>((__builtin_amdgcn_readfirstlane(s.sample_count) + 1u) & 15u);
+        const uint32_t i0 = gi * 4;
+        const int phase = (phase0 + static_cast<int>(i0 - i_first)) & 15;
         if (phase && kmax == 64)
             kmax = 64 - phase;  // end on a multiple of 16 of sample_count_, like every steady block
         kmax &= ~3;
         if (kmax < 8)
-            return;  // the sample loop takes this group
-        const uint32_t i0 = gi * 4;
+            break;  // the sample loop takes this group
+#ifdef MI_BLOCK_PROF
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long ti0 = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (!pre_wait(pre, lane, i0, i0 + static_cast<uint32_t>(kmax))) {
             pre_on = false;  // (final: see steady_block)
             if (lane == 0 && a.pre_timeouts)
                 atomicAdd(a.pre_timeouts, 1u);
-            return;
+            break;
         }
+#ifdef MI_BLOCK_PROF
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long ti1 = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+        bio.prof[0] += ti1 - ti0;            // idle blocks: waiting for the pre-filter wave
+        if (bio.prof_t)
+            bio.prof[7] += ti0 - bio.prof_t;  // ... everything else of a block
+        bio.prof_t = ti1;
+        bio.blocks++;
+#endif
         const unsigned at = (i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u);
         const float C = *(pre_vf32*)&pre->C[at], NFv = *(pre_vf32*)&pre->NF[at];
         const float level = P.using_manual_level ? P.manual_signal_level : P.normal_signal_ratio * NFv;
@@ -1139,12 +1160,11 @@ __device__ __forceinline__ void idle_streak(Ctx& c, const DemodArgs& a, BlockIo&
         const int kc = k & ~3;
         if (kc == 0) {
             skip = 4;
-            return;
+            break;
         }
-        const int last = kc - 1;
         if (lane < kc) {
             if (P.lowpass_enabled) {
-                int h = s.buffer_head + 1 + lane;
+                int h = head + 1 + lane;
                 h = h >= kSquelchRing ? h - kSquelchRing : h;
                 c.ring[h] = C * 0.9f;
             }
@@ -1154,27 +1174,31 @@ __device__ __forceinline__ void idle_streak(Ctx& c, const DemodArgs& a, BlockIo&
             if (bio.has_iqo)
                 bio.iqo[i0 + static_cast<uint32_t>(lane)] = make_float2(0.0f, 0.0f);
         }
-        // the state after step `last`
-        const unsigned atl = (i0 + static_cast<uint32_t>(last)) & (kPreRing - 1u);
+        head = head + kc >= kSquelchRing ? head + kc - kSquelchRing : head + kc;
+        end = i0 + static_cast<uint32_t>(kc);
+        in_batch += static_cast<uint32_t>(kc);
+        if (in_batch == kWaveBatch)
+            MI_END_BATCH();
+        gi += static_cast<uint32_t>(kc / 4);
+        if (kc != kmax) {
+            skip = 4;
+            break;
+        }
+        if (gi >= ngroups)
+            break;
+    }
+    if (end != 0) {  // the state after the last committed step
+        const unsigned atl = (end - 1u) & (kPreRing - 1u);
         s.noise_floor = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->NF[atl])));
         s.moving_avg_cap = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->CAP[atl])));
         s.pre_full = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->F[atl])));
         s.pre_capped = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->C[atl])));
         s.squelch_level_cache = P.using_manual_level ? 0.0f : P.normal_signal_ratio * s.noise_floor;
-        s.sample_count += static_cast<uint32_t>(kc);
-        s.buffer_head = s.buffer_head + kc >= kSquelchRing ? s.buffer_head + kc - kSquelchRing : s.buffer_head + kc;
-        s.buffer_tail = s.buffer_tail + kc >= kSquelchRing ? s.buffer_tail + kc - kSquelchRing : s.buffer_tail + kc;
-        in_batch += static_cast<uint32_t>(kc);
-        if (in_batch == kWaveBatch)
-            MI_END_BATCH();
-        gi += static_cast<uint32_t>(kc / 4);
+        const uint32_t done = end - i_first;
+        s.sample_count += done;
+        s.buffer_head = head;
+        s.buffer_tail = static_cast<int32_t>((static_cast<uint32_t>(s.buffer_tail) + done) % kSquelchRing);
         stale = true;  // the group fetched ahead is behind us now
-        if (kc != kmax) {
-            skip = 4;
-            return;
-        }
-        if (gi >= ngroups)
-            return;
     }
 }
 
