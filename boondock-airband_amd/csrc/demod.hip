@@ -1202,87 +1202,6 @@ __device__ __forceinline__ void idle_streak(Ctx& c, const DemodArgs& a, BlockIo&
     }
 }
 
-// The open plain AM channel (k_demod_pw, audio on the audio wave): what is left for the channel's wave in OPEN is has_signal() --
-// capped_ >= level, from the ring -- and the low-signal count (squelch.cpp:233-245), and handing (level, wavein[j], wavein[j - 100]) to the
-// audio wave.  As in idle_streak() the state is read from the ring after the last committed step and nothing else of the channel is
-// touched inside the loop (the general block keeps ~150 scalars alive around it and reloads them from memory block after block:
-// ≈ 1 100 cycles between two blocks of ≈ 40 instructions).  Blocks start on a multiple of 16 of sample_count_ -- the first
-// noise-floor update of the block is its first step, so the level cache is cleared there and every step's level is ratio x its
-// own noise floor -- else the general block takes one and aligns.  Same decisions, tokens and state as steady_block<true, SQ_OPEN>.
-__device__ __forceinline__ void open_streak_am(Ctx& c, const DemodArgs& a, BlockIo& bio, uint32_t& gi, const uint32_t ngroups, uint32_t& in_batch, uint32_t& batch,
-                                               bool& batch_open, int& skip, bool& stale, LdsPre* pre, bool& pre_on, const int row) {
-    ChanState& s = c.s;
-    const ChanParams& P = c.p;
-    const int lane = c.lane;
-    const float ratio = (s.recent_open_count >= kFlapOpensThreshold && P.flappy_signal_ratio < P.normal_signal_ratio) ? P.flappy_signal_ratio : P.normal_signal_ratio;
-    const float* __restrict__ xrow = bio.magrow + kAgcExtra;
-    float xn = 0.0f, axn = 0.0f;  // the next block's samples, requested a block ahead
-    uint32_t n_at = 0xffffffffu;
-    for (;;) {
-        int kmax = min(64, static_cast<int>(ngroups - gi) * 4);
-        kmax = min(kmax, kWaveBatch - static_cast<int>(in_batch));  // the batch flag is written at a batch's last step
-        kmax &= ~3;
-        if (kmax < 8 || ((__builtin_amdgcn_readfirstlane(s.sample_count) + 1u) & 15u) != 0u)
-            return;  // the general block (it aligns) or the sample loop
-        const uint32_t i0 = gi * 4;
-        const uint32_t li = min(i0 + static_cast<uint32_t>(lane), bio.n - 1u);
-        float x = xn, ax = axn;
-        if (n_at != i0)
-            x = xrow[li], ax = bio.magrow[li];
-        {
-            const uint32_t ni = i0 + static_cast<uint32_t>(kmax);
-            const uint32_t idx = min(ni + static_cast<uint32_t>(lane), bio.n - 1u);
-            xn = xrow[idx], axn = bio.magrow[idx];
-            n_at = ni;
-        }
-        if (!pre_wait(pre, lane, i0, i0 + static_cast<uint32_t>(kmax))) {
-            pre_on = false;  // (final: see steady_block)
-            if (lane == 0 && a.pre_timeouts)
-                atomicAdd(a.pre_timeouts, 1u);
-            return;
-        }
-        const unsigned at = (i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u);
-        const float C = *(pre_vf32*)&pre->C[at], NFv = *(pre_vf32*)&pre->NF[at];
-        const float level = P.using_manual_level ? P.manual_signal_level : ratio * NFv;
-        asm volatile("" : "+v"(x), "+v"(ax));  // (the samples have arrived: out of the memory counter before the stores below enter it)
-        const unsigned long long actmask = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
-        const unsigned long long ge = __ballot(x >= level);
-        const unsigned long long below = ge & ((2ull << lane) - 1ull);
-        const int lsc = below ? lane - (63 - static_cast<int>(__builtin_clzll(below))) : s.low_signal_count + lane + 1;
-        const unsigned long long failm = __ballot(!(C >= level) || lsc >= kLowSignalAbort) & actmask;
-        const int k = failm ? static_cast<int>(__builtin_ctzll(failm)) : kmax;
-        const int kc = k & ~3;
-        if (kc == 0) {
-            skip = 4;
-            return;
-        }
-        const int last = kc - 1;
-        aux_post(c, AUX_BLOCK, static_cast<unsigned>(kc), i0, level, x, ax);
-        // the state after step `last`
-        const unsigned atl = (i0 + static_cast<uint32_t>(last)) & (kPreRing - 1u);
-        s.noise_floor = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->NF[atl])));
-        s.moving_avg_cap = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->CAP[atl])));
-        s.pre_full = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->F[atl])));
-        s.pre_capped = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->C[atl])));
-        s.squelch_level_cache = P.using_manual_level ? 0.0f : ratio * s.noise_floor;
-        s.low_signal_count = __builtin_amdgcn_readlane(lsc, last);
-        s.sample_count += static_cast<uint32_t>(kc);
-        s.buffer_head = s.buffer_head + kc >= kSquelchRing ? s.buffer_head + kc - kSquelchRing : s.buffer_head + kc;
-        s.buffer_tail = s.buffer_tail + kc >= kSquelchRing ? s.buffer_tail + kc - kSquelchRing : s.buffer_tail + kc;
-        in_batch += static_cast<uint32_t>(kc);
-        if (in_batch == kWaveBatch)
-            MI_END_BATCH();
-        gi += static_cast<uint32_t>(kc / 4);
-        stale = true;  // the group fetched ahead is behind us now
-        if (kc != kmax) {
-            skip = 4;
-            return;
-        }
-        if (gi >= ngroups)
-            return;
-    }
-}
-
 // A run of steady blocks in one state (current_state_ == next_state_ == kSt, or whatever it is for kSt < 0): a block never changes
 // the state, so while blocks commit in full nothing but their lengths has to be worked out between them -- the batch end, the
 // 16-step phase of sample_count_, and in the waiting states the step whose delay_ decides.  Returns with gi at the first group no
@@ -1454,10 +1373,6 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
                       if (kPre && st == SQ_CLOSED && pre_on && __builtin_amdgcn_readfirstlane(c.s.closed_sample_count) == kRecentSampleSize &&
                           __builtin_amdgcn_readfirstlane(c.s.recent_open_count) == 0u)
                           idle_streak(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
-                      else if (kPre && st == SQ_OPEN && pre_on && c.split && P.modulation == MI_MOD_AM && !P.using_manual_level &&
-                               __builtin_amdgcn_readfirstlane(c.s.using_post_filter) == 0 &&
-                               ((__builtin_amdgcn_readfirstlane(c.s.sample_count) + 1u) & 15u) == 0u)
-                          open_streak_am(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
                       else if (st == SQ_CLOSED)
                           steady_streak<kPre, SQ_CLOSED>(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
                       else if (st == SQ_OPEN)
