@@ -82,8 +82,7 @@ constexpr unsigned kDescRing = 32;
 enum : unsigned { AUX_BLOCK = 1, AUX_RESET = 2, AUX_BATCH = 3, AUX_QUIT = 4, AUX_FIRST_OPEN = 5, AUX_LAST_OPEN = 6 };
 struct AuxShare {
     float tk_re[kTokRing], tk_im[kTokRing], tk_ax[kTokRing];
-    unsigned d_word[kDescRing];  // type | n << 8
-    unsigned d_arg[kDescRing];   // BLOCK: the first step's index; BATCH: the batch's index
+    unsigned long long d_desc[kDescRing];  // low word: type | n << 8; high word: BLOCK: the first step's index, BATCH: the batch's index
     unsigned d_head;             // descriptors posted (channel wave)
     unsigned d_tail;             // descriptors consumed (audio wave)
     unsigned tk_tail;            // tokens consumed
@@ -665,6 +664,7 @@ __device__ __forceinline__ bool pre_wait(LdsPre* pre, const int lane, const uint
 
 typedef __attribute__((address_space(3))) volatile unsigned aux_vu32;
 typedef __attribute__((address_space(3))) volatile float aux_vf32;
+typedef __attribute__((address_space(3))) volatile unsigned long long aux_vu64;
 __device__ __forceinline__ unsigned aux_peek(const __attribute__((address_space(3))) unsigned* p) {
     return __builtin_amdgcn_readfirstlane(*(const aux_vu32*)p);
 }
@@ -691,10 +691,8 @@ __device__ __forceinline__ void aux_post(Ctx& c, const unsigned type, const unsi
         if (c.p.modulation == MI_MOD_AM)
             *(aux_vf32*)&x->tk_ax[at] = ax;
     }
-    if (c.lane == 0) {
-        *(aux_vu32*)&x->d_word[c.d_head & (kDescRing - 1u)] = type | (n << 8);
-        *(aux_vu32*)&x->d_arg[c.d_head & (kDescRing - 1u)] = arg;
-    }
+    if (c.lane == 0)
+        *(aux_vu64*)&x->d_desc[c.d_head & (kDescRing - 1u)] = static_cast<unsigned long long>(type | (n << 8)) | (static_cast<unsigned long long>(arg) << 32);
     // a wave's LDS operations execute in order: the data before the mark (see pre_wave)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     c.tk_head += n;
@@ -1952,14 +1950,23 @@ __device__ __forceinline__ void audio_wave(const DemodArgs& a, LdsAux* x, const 
     unsigned d_tail = 0, tk_pos = 0;
 
     for (;;) {
-        for (unsigned spin = 0; aux_peek(&x->d_head) == d_tail; ++spin) {
-            __builtin_amdgcn_s_sleep(4);
-            if (spin > 16u * kPreSpin)
+        // The mark and the descriptor it would announce are read in one round trip (in that order: LDS executes a wave's operations
+        // in order, and the posting wave writes the descriptor, waits, then moves the mark -- a mark seen moved means the descriptor
+        // read behind it is the new one; a mark not moved yet, and the descriptor read is thrown away).
+        unsigned word = 0, arg = 0;
+        for (unsigned spin = 0;; ++spin) {
+            const unsigned hv = *(aux_vu32*)&x->d_head;
+            const unsigned long long dv = *(aux_vu64*)&x->d_desc[d_tail & (kDescRing - 1u)];
+            if (static_cast<unsigned>(__builtin_amdgcn_readfirstlane(hv)) != d_tail) {
+                word = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(dv));
+                arg = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(dv >> 32));
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            if (spin > 32u * kPreSpin)
                 return;  // (the channel wave is gone)
         }
         asm volatile("" ::: "memory");
-        const unsigned word = aux_peek(&x->d_word[d_tail & (kDescRing - 1u)]);
-        const unsigned arg = aux_peek(&x->d_arg[d_tail & (kDescRing - 1u)]);
         const unsigned type = word & 0xffu;
         if (type == AUX_BLOCK && am) {
             // AM AGC and audio (rtl_airband.cpp:574-585, 612-641; no CTCSS, no notch, no raw I/Q on these channels).  A clip --
