@@ -63,6 +63,7 @@ struct ChanType {
             p.using_manual_level = kManual;
     }
     static constexpr int raw = kRaw;
+    static constexpr bool am_plain = kMod == MI_MOD_AM && kRaw == 0 && kIqo == 0 && kLp == 0 && kCtcss == 0 && kNotch == 0 && kManual == 0;
 };
 using TyAny = ChanType<-1, -1, -1, -1, -1, -1, -1>;
 using TyAmPlain = ChanType<MI_MOD_AM, 0, 0, 0, 0, 0, 0>;      // what tp.hip also takes: AM, nothing else
@@ -1200,13 +1201,273 @@ __device__ __forceinline__ void idle_streak(Ctx& c, const DemodArgs& a, BlockIo&
     }
 }
 
+// The open plain AM channel with a pre-filter wave (k_demod_pw, k_demod_pw2): what is left for the channel's wave in OPEN is has_signal() --
+// capped_ >= level, from the ring -- and the low-signal count (squelch.cpp:233-245), and then either handing (level, wavein[j],
+// wavein[j - 100]) to the audio wave (kSplit) or the AM AGC and audio themselves (rtl_airband.cpp:574-585, 612-641).  As in idle_streak()
+// nothing else of the channel is touched inside the loop.  Blocks start on a multiple of 16 of sample_count_ -- the first noise-floor
+// update of the block is its first step, so the level cache is cleared there and every step's level is ratio x its own noise floor --
+// else the general block takes one and aligns.  Same decisions, tokens / audio and state as steady_block<true, SQ_OPEN>.
+template <bool kSplit>
+__device__ __forceinline__ void open_streak_am(Ctx& c, const DemodArgs& a, BlockIo& bio, uint32_t& gi, const uint32_t ngroups, uint32_t& in_batch, uint32_t& batch,
+                                               bool& batch_open, int& skip, bool& stale, LdsPre* pre, bool& pre_on, const int row) {
+    ChanState& s = c.s;
+    const ChanParams& P = c.p;
+    const int lane = c.lane;
+    const float ratio = (s.recent_open_count >= kFlapOpensThreshold && P.flappy_signal_ratio < P.normal_signal_ratio) ? P.flappy_signal_ratio : P.normal_signal_ratio;
+    const float* __restrict__ xrow = bio.magrow + kAgcExtra;
+    float xn = 0.0f, axn = 0.0f;  // the next block's samples, requested a block ahead
+    uint32_t n_at = 0xffffffffu;
+    for (;;) {
+        int kmax = min(64, static_cast<int>(ngroups - gi) * 4);
+        kmax = min(kmax, kWaveBatch - static_cast<int>(in_batch));  // the batch flag is written at a batch's last step
+        kmax &= ~3;
+        if (kmax < 8 || ((__builtin_amdgcn_readfirstlane(s.sample_count) + 1u) & 15u) != 0u)
+            return;  // the general block (it aligns) or the sample loop
+        const uint32_t i0 = gi * 4;
+        const uint32_t li = min(i0 + static_cast<uint32_t>(lane), bio.n - 1u);
+        float x = xn, ax = axn;
+        if (n_at != i0)
+            x = xrow[li], ax = bio.magrow[li];
+        {
+            const uint32_t ni = i0 + static_cast<uint32_t>(kmax);
+            const uint32_t idx = min(ni + static_cast<uint32_t>(lane), bio.n - 1u);
+            xn = xrow[idx], axn = bio.magrow[idx];
+            n_at = ni;
+        }
+        if (!pre_wait(pre, lane, i0, i0 + static_cast<uint32_t>(kmax))) {
+            pre_on = false;  // (final: see steady_block)
+            if (lane == 0 && a.pre_timeouts)
+                atomicAdd(a.pre_timeouts, 1u);
+            return;
+        }
+        const unsigned at = (i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u);
+        const float C = *(pre_vf32*)&pre->C[at], NFv = *(pre_vf32*)&pre->NF[at];
+        const float level = ratio * NFv;
+        asm volatile("" : "+v"(x), "+v"(ax));  // (the samples have arrived: out of the memory counter before any store below enters it)
+        const unsigned long long actmask = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
+        const unsigned long long ge = __ballot(x >= level);
+        const unsigned long long below = ge & ((2ull << lane) - 1ull);
+        const int lsc = below ? lane - (63 - static_cast<int>(__builtin_clzll(below))) : s.low_signal_count + lane + 1;
+        bool fail = !(C >= level) || lsc >= kLowSignalAbort;
+        float G = 0.0f, out = 0.0f;
+        if (!kSplit) {  // no audio wave (k_demod_pw2): AM AGC and audio here
+            const bool upd = x > level;
+            const float bA = x * 0.005f;
+            if ((__ballot(!upd) & actmask) == 0ull) {  // every sample above the level: the plain average
+                G = chain_passes(s.agcavgfast, bA, 0.995f, kmax);
+            } else {
+                float Gp = s.agcavgfast;
+                MI_PASSES(0, kmax, {
+                    Gp = shr1(G, Gp);
+                    G = upd ? Gp * 0.995f + bA : Gp;
+                })
+            }
+            const float d = (ax - G) / (G * 1.5f);
+            fail = fail || fabsf(d) > 0.8f;  // the clip feeds back into the AGC: the sample loop takes that step
+            out = d * P.ampfactor;
+            if (out != out)
+                out = 0.0f;
+            else if (out > 1.0f)
+                out = 1.0f;
+            else if (out < -1.0f)
+                out = -1.0f;
+        }
+        const unsigned long long failm = __ballot(fail) & actmask;
+        const int k = failm ? static_cast<int>(__builtin_ctzll(failm)) : kmax;
+        const int kc = k & ~3;
+        if (kc == 0) {
+            skip = 4;
+            return;
+        }
+        const int last = kc - 1;
+        if (kSplit) {
+            aux_post(c, AUX_BLOCK, static_cast<unsigned>(kc), i0, level, x, ax);
+        } else {
+            if (lane < kc) {
+                const uint32_t v = kAgcExtra + i0 + static_cast<uint32_t>(lane);
+                float* dst = (v < bio.n) ? bio.wmain + v : bio.carry + (v - bio.n);
+                *dst = out;
+            }
+            batch_open = true;
+            s.agcavgfast = lane_read(G, last);
+        }
+        // the state after step `last`
+        const unsigned atl = (i0 + static_cast<uint32_t>(last)) & (kPreRing - 1u);
+        s.noise_floor = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->NF[atl])));
+        s.moving_avg_cap = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->CAP[atl])));
+        s.pre_full = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->F[atl])));
+        s.pre_capped = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*(pre_vf32*)&pre->C[atl])));
+        s.squelch_level_cache = ratio * s.noise_floor;
+        s.low_signal_count = __builtin_amdgcn_readlane(lsc, last);
+        s.sample_count += static_cast<uint32_t>(kc);
+        s.buffer_head = s.buffer_head + kc >= kSquelchRing ? s.buffer_head + kc - kSquelchRing : s.buffer_head + kc;
+        s.buffer_tail = s.buffer_tail + kc >= kSquelchRing ? s.buffer_tail + kc - kSquelchRing : s.buffer_tail + kc;
+        in_batch += static_cast<uint32_t>(kc);
+        if (in_batch == kWaveBatch)
+            MI_END_BATCH();
+        gi += static_cast<uint32_t>(kc / 4);
+        stale = true;  // the group fetched ahead is behind us now
+        if (kc != kmax) {
+            skip = 4;
+            return;
+        }
+        if (gi >= ngroups)
+            return;
+    }
+}
+
+// The plain AM channel without helper waves (k_demod_uni: plans of hundreds of rows and more), idle or open: a lean run in the manner of
+// idle_streak() with the pre-filter block (pre_block<false>) and, when open, the AM AGC and audio (rtl_airband.cpp:574-585, 612-641) in
+// the loop.  The state a block hands to the next is a handful of locals; the channel's struct is written once, when the run ends.
+// kOpen: the channel is OPEN (else CLOSED for recent_sample_size_ samples, no recent opening).  Blocks of an open run start on a
+// multiple of 16 of sample_count_ (every step's level is then ratio x its own noise floor).  A step that wants anything else -- the
+// squelch level crossed, the low-signal count at its limit, an AGC clip -- ends the run.
+template <bool kOpen>
+__device__ __forceinline__ void am_plain_run(Ctx& c, const DemodArgs& a, BlockIo& bio, uint32_t& gi, const uint32_t ngroups, uint32_t& in_batch, uint32_t& batch,
+                                             bool& batch_open, int& skip, bool& stale, const int row) {
+    ChanState& s = c.s;
+    const ChanParams& P = c.p;
+    const int lane = c.lane;
+    const float ratio = (kOpen && s.recent_open_count >= kFlapOpensThreshold && P.flappy_signal_ratio < P.normal_signal_ratio) ? P.flappy_signal_ratio
+                                                                                                                              : P.normal_signal_ratio;
+    const float* __restrict__ xrow = bio.magrow + kAgcExtra;
+    float nf = s.noise_floor, cap = s.moving_avg_cap, full = s.pre_full, capd = s.pre_capped, agc = s.agcavgfast;
+    uint32_t sc = __builtin_amdgcn_readfirstlane(s.sample_count);
+    int lowc = s.low_signal_count;
+    uint32_t done = 0;
+    float xn = 0.0f, axn = 0.0f;  // the next block's samples, requested a block ahead
+    uint32_t n_at = 0xffffffffu;
+    for (;;) {
+        int kmax = min(64, static_cast<int>(ngroups - gi) * 4);
+        kmax = min(kmax, kWaveBatch - static_cast<int>(in_batch));  // the batch flag is written at a batch's last step
+        const int phase = static_cast<int>((sc + 1u) & 15u);
+        if (kOpen) {
+            if (phase != 0)
+                break;  // (the general block aligns)
+        } else if (phase && kmax == 64) {
+            kmax = 64 - phase;
+        }
+        kmax &= ~3;
+        if (kmax < 8)
+            break;
+        const uint32_t i0 = gi * 4;
+        const uint32_t li = min(i0 + static_cast<uint32_t>(lane), bio.n - 1u);
+        float x = xn, ax = axn;
+        if (n_at != i0) {
+            x = xrow[li];
+            if (kOpen)
+                ax = bio.magrow[li];
+        }
+        {
+            const uint32_t ni = i0 + static_cast<uint32_t>(kmax);
+            const uint32_t idx = min(ni + static_cast<uint32_t>(lane), bio.n - 1u);
+            xn = xrow[idx];
+            if (kOpen)
+                axn = bio.magrow[idx];
+            n_at = ni;
+        }
+        float F, C, NFv, CAPv;
+        int zf;
+        float nf_b = nf, cap_b = cap;
+        pre_block<false>(P, nf_b, cap_b, full, capd, sc, x, kmax, lane, F, C, NFv, CAPv, zf);
+        const float level = ratio * NFv;
+        const unsigned long long actmask = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
+        bool fail;
+        int lsc = 0;
+        float G = 0.0f, out = 0.0f;
+        if (kOpen) {
+            const unsigned long long ge = __ballot(x >= level);
+            const unsigned long long below = ge & ((2ull << lane) - 1ull);
+            lsc = below ? lane - (63 - static_cast<int>(__builtin_clzll(below))) : lowc + lane + 1;
+            fail = !(C >= level) || lsc >= kLowSignalAbort;
+            const bool upd = x > level;
+            const float bA = x * 0.005f;
+            if ((__ballot(!upd) & actmask) == 0ull) {
+                G = chain_passes(agc, bA, 0.995f, kmax);
+            } else {
+                float Gp = agc;
+                MI_PASSES(0, kmax, {
+                    Gp = shr1(G, Gp);
+                    G = upd ? Gp * 0.995f + bA : Gp;
+                })
+            }
+            const float d = (ax - G) / (G * 1.5f);
+            fail = fail || fabsf(d) > 0.8f;  // the clip feeds back into the AGC: the sample loop takes that step
+            out = d * P.ampfactor;
+            if (out != out)
+                out = 0.0f;
+            else if (out > 1.0f)
+                out = 1.0f;
+            else if (out < -1.0f)
+                out = -1.0f;
+        } else {
+            fail = C >= level;
+        }
+        asm volatile("" : "+v"(xn));  // (the next block's samples have arrived: out of the memory counter before the stores below enter it)
+        const unsigned long long failm = __ballot(fail) & actmask;
+        const int k = failm ? static_cast<int>(__builtin_ctzll(failm)) : kmax;
+        const int kc = k & ~3;
+#ifdef MI_LEAN_DEBUG
+        if (kOpen && row == 0 && gi < 3000 && kc != kmax && lane == k)
+            printf("  block i0 %u kmax %d fails at lane %d: C %g level %g lsc %d d-clip %d x %g\n", i0, kmax, k, C, level, lsc, (int)(fabsf((ax - G) / (G * 1.5f)) > 0.8f), x);
+#endif
+        if (kc == 0) {
+            skip = 4;
+            break;
+        }
+        const int last = kc - 1;
+        if (lane < kc) {
+            const uint32_t v = kAgcExtra + i0 + static_cast<uint32_t>(lane);
+            float* dst = (v < bio.n) ? bio.wmain + v : bio.carry + (v - bio.n);
+            *dst = out;
+        }
+        if (kOpen)
+            batch_open = true;
+        nf = lane_read(NFv, last), cap = lane_read(CAPv, last), full = lane_read(F, last), capd = lane_read(C, last);
+        if (kOpen) {
+            agc = lane_read(G, last);
+            lowc = __builtin_amdgcn_readlane(lsc, last);
+        }
+        sc += static_cast<uint32_t>(kc);
+        done += static_cast<uint32_t>(kc);
+        in_batch += static_cast<uint32_t>(kc);
+        if (in_batch == kWaveBatch)
+            MI_END_BATCH();
+        gi += static_cast<uint32_t>(kc / 4);
+        if (kc != kmax) {
+            skip = 4;
+            break;
+        }
+        if (gi >= ngroups)
+            break;
+    }
+#ifdef MI_LEAN_DEBUG
+    if (kOpen && row == 0 && lane == 0 && gi < 3000)
+        printf("lean open run: gi %u done %u sc %u in_batch %u skip %d\n", gi, done, sc, in_batch, skip);
+#endif
+    if (done != 0) {
+        s.noise_floor = nf, s.moving_avg_cap = cap, s.pre_full = full, s.pre_capped = capd;
+        s.squelch_level_cache = ratio * nf;
+        s.sample_count = sc;
+        s.buffer_head = static_cast<int32_t>((static_cast<uint32_t>(s.buffer_head) + done) % kSquelchRing);
+        s.buffer_tail = static_cast<int32_t>((static_cast<uint32_t>(s.buffer_tail) + done) % kSquelchRing);
+        if (kOpen) {
+            s.agcavgfast = agc;
+            s.low_signal_count = lowc;
+        }
+        stale = true;  // the group fetched ahead is behind us now
+    }
+}
+
 // A run of steady blocks in one state (current_state_ == next_state_ == kSt, or whatever it is for kSt < 0): a block never changes
 // the state, so while blocks commit in full nothing but their lengths has to be worked out between them -- the batch end, the
 // 16-step phase of sample_count_, and in the waiting states the step whose delay_ decides.  Returns with gi at the first group no
 // block took (possibly ngroups); `skip` says how many groups the sample loop should take before blocks are tried again.
+// lean_next: a leaner run exists for this state once sample_count_ sits on a multiple of 16: hand back after the block that aligns it.
 template <bool kPre, int kSt>
 __device__ __forceinline__ void steady_streak(Ctx& c, const DemodArgs& a, BlockIo& bio, uint32_t& gi, const uint32_t ngroups, uint32_t& in_batch,
-                                              uint32_t& batch, bool& batch_open, int& skip, bool& stale, LdsPre* pre, bool& pre_on, const int row) {
+                                              uint32_t& batch, bool& batch_open, int& skip, bool& stale, LdsPre* pre, bool& pre_on, const int row,
+                                              const bool lean_next = false, bool* again = nullptr) {
     const ChanParams& P = c.p;
     const int st = kSt >= 0 ? kSt : __builtin_amdgcn_readfirstlane(c.s.current_state);
     const bool lpz = P.lowpass_enabled && bio.has_z;
@@ -1270,6 +1531,10 @@ __device__ __forceinline__ void steady_streak(Ctx& c, const DemodArgs& a, BlockI
         }
         if (gi >= ngroups)
             return;
+        if (lean_next && ((__builtin_amdgcn_readfirstlane(c.s.sample_count) + 1u) & 15u) == 0u) {
+            *again = true;  // (nothing failed: the caller looks at the state again instead of taking a group through the sample loop)
+            return;
+        }
     }
 }
 
@@ -1368,7 +1633,34 @@ __device__ __forceinline__ void demod_body(const DemodArgs& a, LdsPre* pre, LdsA
                   const int st = __builtin_amdgcn_readfirstlane(c.s.current_state);
                   const int nxt = __builtin_amdgcn_readfirstlane(c.s.next_state);
                   if (st == nxt) {  // (a branch on the state here, and the blocks' own tests of it fold away)
-                      if (kPre && st == SQ_CLOSED && pre_on && __builtin_amdgcn_readfirstlane(c.s.closed_sample_count) == kRecentSampleSize &&
+                      if (!kPre && T::am_plain && st == SQ_CLOSED && __builtin_amdgcn_readfirstlane(c.s.closed_sample_count) == kRecentSampleSize &&
+                          __builtin_amdgcn_readfirstlane(c.s.recent_open_count) == 0u)
+                          am_plain_run<false>(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, row);
+                      else if (!kPre && T::am_plain && st == SQ_OPEN && __builtin_amdgcn_readfirstlane(c.s.using_post_filter) == 0) {
+                          if (((__builtin_amdgcn_readfirstlane(c.s.sample_count) + 1u) & 15u) != 0u) {  // (one general block aligns it)
+                              bool again = false;
+                              steady_streak<kPre, SQ_OPEN>(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row, true, &again);
+                              if (again && gi < ngroups) {
+                                  --gi;  // the loop increment
+                                  continue;
+                              }
+                          } else {
+                              am_plain_run<true>(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, row);
+                          }
+                      } else if (kPre && st == SQ_OPEN && pre_on && TyAmPlain::matches(P) && __builtin_amdgcn_readfirstlane(c.s.using_post_filter) == 0) {
+                          if (((__builtin_amdgcn_readfirstlane(c.s.sample_count) + 1u) & 15u) != 0u) {  // (one general block aligns it)
+                              bool again = false;
+                              steady_streak<kPre, SQ_OPEN>(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row, true, &again);
+                              if (again && gi < ngroups) {
+                                  --gi;  // the loop increment
+                                  continue;
+                              }
+                          } else if (c.split) {
+                              open_streak_am<true>(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
+                          } else {
+                              open_streak_am<false>(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
+                          }
+                      } else if (kPre && st == SQ_CLOSED && pre_on && __builtin_amdgcn_readfirstlane(c.s.closed_sample_count) == kRecentSampleSize &&
                           __builtin_amdgcn_readfirstlane(c.s.recent_open_count) == 0u)
                           idle_streak(c, a, bio, gi, ngroups, in_batch, batch, batch_open, skip, stale, pre, pre_on, row);
                       else if (st == SQ_CLOSED)
@@ -1832,6 +2124,9 @@ __device__ __forceinline__ void full_wave(const DemodArgs& a, LdsPre* pre, const
 }
 
 // The pre-filter wave of k_demod_pw: the recurrence of steady_block()'s first phase, block after block over the whole call.
+// kFullWave: full_ comes from the full_ wave's ring (k_demod_pw); else this wave walks it too (k_demod_pw2) and stays within the
+// ring's reach of the channel wave itself.
+template <bool kFullWave>
 __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const int lane) {
     const int row = demod_row(a, static_cast<int>(blockIdx.x));
     const ChanParams P = a.cp[row % a.nch];
@@ -1842,6 +2137,7 @@ __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const 
     float nf = s0.noise_floor, cap = s0.moving_avg_cap, full = s0.pre_full, capd = s0.pre_capped;
     uint32_t sc = s0.sample_count;
     float xn = xrow[min(static_cast<uint32_t>(lane), n - 1u)];  // the next block's samples, requested a block ahead
+    uint32_t reach = 0;  // (no full_ wave) steps below this are within the ring's reach of the channel wave as last seen
 #ifdef MI_BLOCK_PROF
     unsigned long long pw_t0 = __builtin_readcyclecounter(), pw_wait = 0, pw_load = 0, pw_per = 0, pw_tail = 0, pw_fast = 0, pw_n = 0;
 #endif
@@ -1859,11 +2155,21 @@ __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const 
         pw_load += pw_b - pw_a;
 #endif
         xn = xrow[min(i0 + 64u + static_cast<uint32_t>(lane), n - 1u)];
-        // full_ of these steps from the full_ wave (usually blocks ahead)
-        for (unsigned spin = 0; pre_peek(&pre->f_done) < i0 + static_cast<uint32_t>(kmax); ++spin) {
-            __builtin_amdgcn_s_sleep(1);
-            if (spin > 4u * kPreSpin)
-                return;
+        if (kFullWave) {  // full_ of these steps from the full_ wave (usually blocks ahead)
+            for (unsigned spin = 0; pre_peek(&pre->f_done) < i0 + static_cast<uint32_t>(kmax); ++spin) {
+                __builtin_amdgcn_s_sleep(1);
+                if (spin > 4u * kPreSpin)
+                    return;
+            }
+        } else if (i0 + 64u > reach) {  // stay within the ring's reach of the channel wave (it posts its position before it waits for this wave)
+            for (unsigned idle = 0;; ++idle) {
+                reach = pre_peek(&pre->m_pos) + (kPreRing - 64u);
+                if (i0 + 64u <= reach)
+                    break;
+                __builtin_amdgcn_s_sleep(2);
+                if (idle > 4u * kPreSpin)
+                    return;  // (the channel wave is gone or stuck: it computes its own values when its wait runs out)
+            }
         }
         asm volatile("" ::: "memory");
 #ifdef MI_BLOCK_PROF
@@ -1873,17 +2179,19 @@ __device__ __forceinline__ void pre_wave(const DemodArgs& a, LdsPre* pre, const 
             pw_b = t_;
         }
 #endif
-        float F = *(pre_vf32*)&pre->F[(i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u)];
+        float F = kFullWave ? *(pre_vf32*)&pre->F[(i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u)] : 0.0f;
         float C, NFv, CAPv;
         int zf;
-        pre_block<true>(P, nf, cap, full, capd, sc, x, kmax, lane, F, C, NFv, CAPv, zf);
+        pre_block<kFullWave>(P, nf, cap, full, capd, sc, x, kmax, lane, F, C, NFv, CAPv, zf);
 #ifdef MI_BLOCK_PROF
         unsigned long long pw_c = __builtin_readcyclecounter();
         pw_per += pw_c - pw_b;
 #endif
         if (lane < kmax) {
             const unsigned at = (i0 + static_cast<uint32_t>(lane)) & (kPreRing - 1u);
-            *(pre_vf32*)&pre->C[at] = C, *(pre_vf32*)&pre->NF[at] = NFv, *(pre_vf32*)&pre->CAP[at] = CAPv;  // (F is there already)
+            *(pre_vf32*)&pre->C[at] = C, *(pre_vf32*)&pre->NF[at] = NFv, *(pre_vf32*)&pre->CAP[at] = CAPv;
+            if (!kFullWave)
+                *(pre_vf32*)&pre->F[at] = F;
         }
         // The ring values before the mark.  A wave's LDS operations are issued and executed in order, so the compiler barrier is what
         // matters; the wait makes the order explicit at the price of the LDS counter only (a workgroup fence would also wait for
@@ -2225,10 +2533,29 @@ __global__ MI_PW_BOUNDS void k_demod_pw(const DemodArgs a) {
         return;
     }
     if (threadIdx.x >= 64) {
-        pre_wave(a, pre, static_cast<int>(threadIdx.x) - 64);
+        pre_wave<true>(a, pre, static_cast<int>(threadIdx.x) - 64);
         return;
     }
     demod_dispatch<true, true>(a, pre, aux);
+}
+
+// Two waves per channel: the channel itself, audio and all, and the pre-filter wave ahead of it (full_ included).  For plans of more
+// rows than CUs, up to 1 024: two waves per row leave every SIMD room for stage 1 of the next call, which four waves with a register
+// file each do not.
+#ifndef MI_PW2_EU
+#define MI_PW2_EU 4
+#endif
+__global__ __launch_bounds__(128, MI_PW2_EU) void k_demod_pw2(const DemodArgs a) {
+    __shared__ PreShare sh_mem2;
+    LdsPre* const pre = (LdsPre*)&sh_mem2;
+    if (threadIdx.x == 0)
+        pre->h_done = 0, pre->m_pos = 0, pre->f_done = 0;
+    __syncthreads();
+    if (threadIdx.x >= 64) {
+        pre_wave<false>(a, pre, static_cast<int>(threadIdx.x) - 64);
+        return;
+    }
+    demod_dispatch<true, true>(a, pre, nullptr);
 }
 
 __global__ void k_init_state(ChanState* st, float* carry, float* sq_ring, float* ctcss_q, const ChanParams* cp, int nstreams, int nch,
@@ -2299,7 +2626,11 @@ hipError_t launch_demod(const DemodArgs& a, hipStream_t s) {
     if (rows == 0 || a.nsteps == 0)
         return hipSuccess;
     const int blocks = (rows + a.lanes_per_wave - 1) / a.lanes_per_wave;
-    if (a.lanes_per_wave == 1 && a.pre_wave && a.steady_blocks)
+    if (a.lanes_per_wave == 1 && a.pre_wave == 2 && a.steady_blocks) {
+        DemodArgs a2 = a;
+        a2.audio_wave = 0;  // (the channel wave keeps the audio)
+        hipLaunchKernelGGL(k_demod_pw2, dim3(blocks), dim3(128), 0, s, a2);
+    } else if (a.lanes_per_wave == 1 && a.pre_wave && a.steady_blocks)
         hipLaunchKernelGGL(k_demod_pw, dim3(blocks), dim3(256), 0, s, a);
     else if (a.lanes_per_wave == 1)
         hipLaunchKernelGGL(k_demod_uni, dim3(blocks), dim3(64), 0, s, a);

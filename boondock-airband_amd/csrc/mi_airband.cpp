@@ -301,7 +301,7 @@ void tuning_from_env(mi_demod* h) {
     if (const char* e = get("MI_AIRBAND_CORE_GUESS"))
         h->opt_core_guess = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_PRE_WAVE"))
-        h->opt_pre_wave = std::atoi(e) < 0 ? -1 : (std::atoi(e) != 0 ? 1 : 0);
+        h->opt_pre_wave = std::atoi(e) < 0 ? -1 : std::min(2, std::atoi(e));
     if (const char* e = get("MI_AIRBAND_MIXED"))
         h->opt_mixed = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_AUDIO_WAVE"))
@@ -458,7 +458,8 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
     // +12 %); with a thousand rows and more the machine is full and a second wave per row only takes LDS and issue slots from
     // stage 1 (32 streams: +-0, 64 streams: -27 %)
     // (round 3: four waves per channel, each with a SIMD's register file to itself: one channel per CU, so up to 256 rows)
-    da.pre_wave = (h->opt_pre_wave < 0 ? h->rows <= 256 : h->opt_pre_wave != 0) ? 1 : 0;
+    // ... and two waves per channel (the channel with its audio, the pre-filter wave) up to 1 024 rows: 2 = k_demod_pw2
+    da.pre_wave = h->opt_pre_wave < 0 ? (h->rows <= 256 ? 1 : (h->rows <= 1024 ? 2 : 0)) : std::min(2, h->opt_pre_wave);
     da.audio_wave = h->opt_audio_wave ? 1 : 0;
     da.pre_timeouts = h->d_pre_timeouts;
 
@@ -1977,7 +1978,7 @@ int mi_demod_set_option(mi_demod* h, int option, int value) {
             h->opt_reserve_cus = value < 0 ? -1 : value;
             return MI_OK;
         case MI_OPT_PRE_WAVE:
-            h->opt_pre_wave = value < 0 ? -1 : (value != 0 ? 1 : 0);
+            h->opt_pre_wave = value < 0 ? -1 : std::min(2, value);
             return MI_OK;
         case MI_OPT_LANE_FFT_JIT:
             h->opt_l64_jit = value != 0;

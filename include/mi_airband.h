@@ -269,8 +269,9 @@ enum {
                                * for the state that call's tail leaves; the scan checks them against it afterwards */
     MI_OPT_PRE_WAVE = 14,     /* serial stage 2 with one channel per wave: further waves of the channel's workgroup walk the squelch's pre-filter
                                * averages and noise floor over the call ahead of the channel's own wave (demod.hip, k_demod_pw: the full_ wave
-                               * and the pre-filter wave).  -1 (default): up to 256 rows (streams x channels: one channel per CU), 0 never,
-                               * 1 always */
+                               * and the pre-filter wave).  -1 (default): up to 256 rows (streams x channels: one channel per CU) four waves per
+                               * channel, up to 1 024 rows two (k_demod_pw2: the channel with its audio, and one wave for the pre-filter pair),
+                               * beyond that none; 0 never, 1 four waves, 2 two waves */
     MI_OPT_RESERVE_CUS = 15,  /* time-parallel path: the wide passes of a call (stage 1, aggregates, segment pass) keep off this many CUs, which stay
                                * free for the core chains and the latency-bound tail kernels of the neighbouring calls (they need few waves but
                                * most of a SIMD's registers each, and otherwise wait for a wide wave to retire).  -1 (default): 32 on handles of

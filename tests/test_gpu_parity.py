@@ -838,7 +838,7 @@ def test_pre_filter_wave_same_bits_and_state(pkg, seed, per_call):
     nbat = 12
     iq = _zoo_capture(pkg, dev, centre, chans, nbat, seed)
     res = {}
-    for on in (1, 0):
+    for on in (1, 2, 0):  # four waves per channel (k_demod_pw), two (k_demod_pw2: the channel with its audio + the pre-filter wave), one
         d = pkg.Demod(dev, chans, max_batches=per_call)
         d.set_option(pkg.OPT_PRE_WAVE, on)
         outs = []
@@ -849,12 +849,13 @@ def test_pre_filter_wave_same_bits_and_state(pkg, seed, per_call):
         assert d.pre_wave_timeouts() == 0, "a channel wave gave up waiting for its pre-filter wave"
         d.close()
         res[on] = outs
-    for call, (a, b) in enumerate(zip(res[1], res[0])):
-        assert_same(a[0], b[0], f"audio, call {call}")
-        assert_same(a[1], b[1], f"flags, call {call}")
-        assert_same(a[2], b[2], f"raw I/Q, call {call}")
-        assert a[3] == b[3], f"statistics differ after call {call}"
-        assert_same(a[4], b[4], f"checkpoint state, call {call}")
+    for on in (1, 2):
+        for call, (a, b) in enumerate(zip(res[on], res[0])):
+            assert_same(a[0], b[0], f"audio, call {call}, {on}")
+            assert_same(a[1], b[1], f"flags, call {call}, {on}")
+            assert_same(a[2], b[2], f"raw I/Q, call {call}, {on}")
+            assert a[3] == b[3], f"statistics differ after call {call}, {on}"
+            assert_same(a[4], b[4], f"checkpoint state, call {call}, {on}")
     nb, owo, oaxc, oiq = oracle_run(dev, chans, iq, nbat, want_iq=True)
     wo = np.concatenate([o[0][:, :, :per_call * WAVE_BATCH] for o in res[1]], axis=2)
     axc = np.concatenate([o[1] for o in res[1]], axis=2)
