@@ -1283,7 +1283,10 @@ __global__ __launch_bounds__(512) void k_tp_core2(const TpArgs a) {
     int n_rounds = 0;
     CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_idle = 0, t_mark = 0, t_finish = 0; int n_groups = 0, n_restarts = 0; bool idling = false;)
     // blocks wave 0 may be ahead of wave 1: at least two groups (wave 1 waits for the whole group it is in), at most the ring
-    const uint32_t lead = max(128u, min(static_cast<uint32_t>(a.core_lead > 0 ? a.core_lead : 768), kNfRing - 128u));
+    // (as far as the ring reaches: the decay waves find a decay when wave 0 passes its start, and the further ahead of wave 1 that is,
+    //  the more of the decay's chain -- 11-17 us -- is walked before wave 1 needs it: 768 -> 1920 blocks, 1.24 -> 1.17-1.19 ms per
+    //  64-s call; rings of 4096 blocks with more lead gain nothing: a restart then throws too much away)
+    const uint32_t lead = max(128u, min(static_cast<uint32_t>(a.core_lead > 0 ? a.core_lead : 1920), kNfRing - 128u));
     unsigned quit = share_peek(&sh->quit), rs = share_peek(&sh->rb_seq), w1_pos = share_peek(&sh->w1_pos),
              op_done = min(share_peek(&sh->fetch_next[0]), share_peek(&sh->fetch_next[1]));
     for (;;) {
