@@ -119,7 +119,7 @@ struct mi_demod {
     int opt_core_lead = 0;       // (diagnostic, MI_AIRBAND_CORE_LEAD) blocks the noise-floor wave may run ahead, 0 = default
     int opt_agc_hint = 1;        // (diagnostic, MI_AIRBAND_AGC_HINT=0) segment lanes start from agcavgfast = 0.5 instead of the channel's last value
     int opt_core_decay = 1;      // (diagnostic, MI_AIRBAND_CORE_DECAY=0) no decay waves: the walking wave steps every decay itself
-    int opt_core_guess = 1;      // (diagnostic, MI_AIRBAND_CORE_GUESS=0) the noise-floor wave walks systolic passes only, no guess-and-verify rounds
+    int opt_core_guess = 1;      // (diagnostic, MI_AIRBAND_CORE_GUESS) 0: the noise-floor wave walks systolic passes only; 2: the first guess-and-verify rounds (groups of 64)
     bool opt_core_split = true;  // MI_OPT_CORE_SPLIT: noise-floor passes of the core chain on their own wave (k_tp_core2)
     bool core_split_ok = false;  // ... the plan allows it: automatic squelch levels with a cap factor >= 1 on every channel
     bool opt_l64 = true;      // MI_OPT_LANE_FFT: the lane-resident stage 1 at N = 512 where the plan allows it
@@ -299,7 +299,7 @@ void tuning_from_env(mi_demod* h) {
     if (const char* e = get("MI_AIRBAND_CORE_DECAY"))
         h->opt_core_decay = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_CORE_GUESS"))
-        h->opt_core_guess = std::atoi(e) != 0;
+        h->opt_core_guess = std::max(0, std::min(2, std::atoi(e)));
     if (const char* e = get("MI_AIRBAND_PRE_WAVE"))
         h->opt_pre_wave = std::atoi(e) < 0 ? -1 : std::min(2, std::atoi(e));
     if (const char* e = get("MI_AIRBAND_MIXED"))

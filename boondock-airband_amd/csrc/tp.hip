@@ -375,6 +375,168 @@ __device__ __forceinline__ float nf_chain_guess64(float& nf, const float op, NfG
     return vnf;
 }
 
+// ---- the same walk with the round written for a lone wave (round 3, tools/micro/lane_cost.hip, tools/round_cost.hip) ----
+// What a round costs is not its instruction count but its dependent chain: 3.5 ns per dependent vector instruction, 8 ns for every value
+// that goes from the vector unit through a scalar instruction and back, 10 ns per taken branch -- the round above is 140-170 ns, its
+// bookkeeping around it as much again.  Here:
+//   * groups of 63 blocks, so that a lane's class (block mod 3) never changes and the pattern vectors live across groups: P (the predicted
+//     increments of the lanes before this one), P1 = P + the lane's own, pinc = the lane's own -- recomputed only when a class learns a new
+//     increment or a run below the floor resets them;
+//   * the guess is one add (base + P), the check is made by the PRODUCING lane (result - guess == pinc: no DPP, no shift of the ballot),
+//     EXEC = the lanes behind kk (the compare returns 0 for the settled ones, the settled values are kept by a plain move), lane 62's pinc is
+//     a value no step can produce, so the group end needs no extra bit;
+//   * base of the next round (result of lane `last` - P of lane last + 1) is read with the same lane select as everything else: one
+//     scalar round trip per round (compare -> find first -> readlane), 34 ns for a round that ends the group, 60 ns for one that ends early
+//     and goes on (a lone step below the floor);
+//   * an exception the pattern did not have and a run below the floor leave the assembly block for the C++ around it.
+// Soundness is the argument of nf_chain_guess64: lane kk's input is exact, and result_j - guess_j == pinc_j means result_j == guess_{j+1}
+// because guess_{j+1} - guess_j = P_{j+1} - P_j = pinc_j by construction (exact in 32 bits: increments < 2^22, 21 triples at most).
+struct NfGuessL {           // per lane (loop-carried scalars end up in vector registers anyway)
+    uint32_t P, P1, pinc;   // see above
+    uint32_t key;           // the same on every lane: (nf bits >> 23) << 22 | the plain self step's increment in that binade; ~0: nothing valid
+};
+struct NfLaneConst {
+    uint32_t q, a, b, cls;  // lane / 3, class >= 1, class == 2, class
+};
+__device__ __forceinline__ NfLaneConst nf_lane_const(const int lane) {
+    NfLaneConst lc;
+    lc.q = static_cast<uint32_t>(lane) / 3u;
+    lc.cls = static_cast<uint32_t>(lane) - 3u * lc.q;
+    lc.a = lc.cls >= 1u ? 1u : 0u;
+    lc.b = lc.cls == 2u ? 1u : 0u;
+    return lc;
+}
+__device__ __forceinline__ uint32_t sel_mask(const uint32_t a, const uint32_t b, const unsigned long long mask) {  // lane in mask ? b : a
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+constexpr unsigned long long kGuessLast = 1ull << 62;
+// the pattern vectors for the increments h0, h1, h2 of the three classes (wave-uniform)
+__device__ __forceinline__ void nf_pattern(NfGuessL& gs, const NfLaneConst& lc, const uint32_t h0, const uint32_t h1, const uint32_t h2) {
+    gs.P = mul24(lc.q, h0 + h1 + h2) + mul24(lc.a, h0) + mul24(lc.b, h1);
+    const uint32_t own = sel_mask(sel_mask(h0, h1, 0x2492492492492492ull), h2, 0x4924924924924924ull);
+    gs.P1 = gs.P + own;
+    gs.pinc = sel_mask(own, 0xffffffffu, kGuessLast);  // (a step's increment is < 2^23)
+}
+// ... for the plain increment on every class
+__device__ __forceinline__ void nf_pattern_flat(NfGuessL& gs, const int lane, const uint32_t inc) {
+    gs.P = mul24(static_cast<uint32_t>(lane), inc);
+    gs.P1 = gs.P + inc;
+    gs.pinc = sel_mask(inc, 0xffffffffu, kGuessLast);
+}
+constexpr uint32_t kGuessGroup = 63;
+// Returns per lane the noise floor after the lane's block (lanes 0 .. 62), leaves the floor after block 62 in nf.
+__device__ __forceinline__ float nf_chain_guess63(float& nf, const float op, NfGuessL& gs, const NfLaneConst& lc, const int lane, int& n_rounds) {
+    const float k97 = 0.97f, k03 = static_cast<float>(1.0 - static_cast<double>(0.97f));
+    uint32_t nfb = __builtin_amdgcn_readfirstlane(__float_as_uint(nf));
+    float vnf = nf;
+    const uint32_t key = __builtin_amdgcn_readfirstlane(gs.key);
+    uint32_t inc_ = key & 0x3fffffu;
+    if (__builtin_expect((nfb >> 23) != (key >> 22), 0)) {  // another binade (or nothing valid yet): the increment and the pattern afresh
+        const uint32_t inc = inc_ = __builtin_amdgcn_readfirstlane(__float_as_uint(__uint_as_float(nfb) + 1e-6f)) - nfb;
+        if (inc - 1u >= (1u << 22) - 1u) {  // (nf below ~2e-6 or at the top of its binade: not worth a pattern) the passes
+            vnf = nf_chain_min64(nf, op);
+            nf = rl(vnf, static_cast<int>(kGuessGroup) - 1);
+            gs.key = 0xffffffffu;
+            n_rounds += 64;
+            return vnf;
+        }
+        gs.key = (nfb >> 23) << 22 | inc;
+        nf_pattern_flat(gs, lane, inc);
+    }
+    const uint32_t inc = __builtin_amdgcn_readfirstlane(inc_);  // (the compiler takes the merge of the two for divergent)
+    uint32_t kk = 0, early = 0, odd = 0, base = nfb;            // (P of lane 0 is 0)
+    for (;;) {
+        // (temporaries in fixed registers: with more than one vector output the compiler takes every output of the block, the scalar
+        //  ones included, for divergent and does the bookkeeping below in vector code)
+        //  v120 guess  v121 result  v122 result - guess  v123 result - P1  v124, v125 products
+        uint32_t last, dl, run, what;
+        asm volatile(
+            "s_lshl_b64 exec, -1, %[kk]\n"
+            "1:\n"
+            "v_add_u32 v120, %[base], %[P]\n"
+            "v_min_f32 v125, %[op], v120\n"
+            "v_mul_f32 v124, %[k97], v120\n"
+            "v_mul_f32 v125, %[k03], v125\n"
+            "v_add_f32 v124, v124, v125\n"
+            "v_add_f32 v121, 0x358637bd, v124\n"
+            "v_sub_u32 v122, v121, v120\n"
+            "v_cmp_ne_u32 vcc, v122, %[pinc]\n"
+            "v_mov_b32 %[vnf], v121\n"
+            "v_sub_u32 v123, v121, %[P1]\n"
+            "s_ff1_i32_b64 %[last], vcc\n"
+            "s_add_i32 %[kk], %[last], 1\n"
+            "s_lshl_b64 exec, -1, %[kk]\n"
+            "s_cmp_eq_u32 %[last], 62\n"
+            "s_mov_b32 %[what], 0\n"
+            "v_readlane_b32 %[base], v123, %[last]\n"
+            "v_readlane_b32 %[nfb], v121, %[last]\n"
+            "s_cbranch_scc1 2f\n"                       // the group is done
+            "v_readlane_b32 %[dl], v122, %[last]\n"
+            "v_cmp_lt_f32 vcc, %[op], v120\n"
+            "s_add_i32 %[early], %[early], 1\n"
+            "s_sub_i32 s20, %[dl], %[incm1]\n"
+            "s_cmp_le_u32 s20, 2\n"
+            "s_cbranch_scc1 4f\n"                       // an exception the pattern did not have
+            "6:\n"
+            "s_bitcmp1_b64 vcc, %[kk]\n"
+            "s_cbranch_scc1 5f\n"                       // a run below the floor
+            "s_cmp_ge_u32 %[early], 8\n"
+            "s_cbranch_scc0 1b\n"                       // a lone step below the floor: the next round
+            "5:\n"
+            "s_lshr_b64 s[20:21], vcc, %[kk]\n"
+            "s_not_b64 s[20:21], s[20:21]\n"
+            "s_ff1_i32_b64 %[run], s[20:21]\n"         // (-1: every lane behind)
+            "s_sub_i32 s20, 63, %[kk]\n"
+            "s_min_u32 %[run], %[run], s20\n"
+            "s_cmp_ge_u32 %[early], 8\n"
+            "s_cselect_b32 %[run], s20, %[run]\n"      // after eight early ends the rest of the group
+            "s_mov_b32 %[what], 2\n"
+            "s_branch 2f\n"
+            "4:\n"                                      // ... a lone one is passed like a lone step below the floor (the pattern stays as it
+            "s_add_i32 %[odd], %[odd], 1\n"            //     is: learning and unlearning it costs more than the round), the second one of
+            "s_cmp_ge_u32 %[odd], 2\n"                 //     a group is the start or the end of a train: the class of `last` learns it
+            "s_cbranch_scc0 6b\n"
+            "s_mov_b32 %[what], 1\n"
+            "2:\n"
+            "s_mov_b64 exec, -1\n"
+            : [vnf] "+v"(vnf), [base] "+s"(base), [nfb] "+s"(nfb), [last] "=&s"(last), [dl] "=&s"(dl), [run] "=&s"(run), [what] "=&s"(what), [kk] "+s"(kk),
+              [early] "+s"(early), [odd] "+s"(odd)
+            : [P] "v"(gs.P), [P1] "v"(gs.P1), [pinc] "v"(gs.pinc), [op] "v"(op), [k97] "s"(k97), [k03] "s"(k03), [incm1] "s"(inc - 1u)
+            : "vcc", "scc", "s20", "s21", "v120", "v121", "v122", "v123", "v124", "v125");
+        if (what == 0u)
+            break;
+        if (what == 1u) {  // the class of `last` takes the increment seen
+            const uint32_t c = __builtin_amdgcn_readlane(lc.cls, last);
+            const uint32_t h0 = __builtin_amdgcn_readlane(gs.pinc, 0), h1 = __builtin_amdgcn_readlane(gs.pinc, 1), h2 = __builtin_amdgcn_readlane(gs.pinc, 2);
+            nf_pattern(gs, lc, c == 0u ? dl : h0, c == 1u ? dl : h1, c == 2u ? dl : h2);
+            base = nfb - __builtin_amdgcn_readlane(gs.P, kk);
+            odd = 0;
+            continue;
+        }
+        // Steps below the floor come in runs (full_ stays under the floor for a few blocks) and each one is a misprediction of its own:
+        // the run behind `last` (judged by the guesses, i.e. from above -- a lane that is not below the floor after all is walked correctly
+        // just the same) is walked by systolic passes, and after eight early ends the rest of the group goes that way.
+        {
+            float w = vnf;
+            if (static_cast<uint32_t>(lane) >= kk)
+                w = nf_chain_min(__uint_as_float(nfb), op, static_cast<int>(run));
+            if (static_cast<uint32_t>(lane) - kk < run)  // lanes kk .. kk + run - 1
+                vnf = w;
+            kk += run;
+            nfb = __builtin_amdgcn_readlane(__float_as_uint(vnf), kk - 1u);
+            if (kk >= kGuessGroup)
+                break;
+            nf_pattern_flat(gs, lane, inc);  // (behind a run the pattern starts afresh)
+            base = nfb - __builtin_amdgcn_readlane(gs.P, kk);
+        }
+    }
+    n_rounds += static_cast<int>(early) + 1;
+    nf = __uint_as_float(nfb);
+    return vnf;
+}
+
 struct CoreGroup {  // what lane l holds for block g0 + l
     float fe, fm, x0, xm;
 };
@@ -1280,8 +1442,11 @@ __global__ __launch_bounds__(512) void k_tp_core2(const TpArgs a) {
     uint32_t blk = a.blk0;
     unsigned ack = 0, idle = 0;
     NfGuess gs = {0u};
+    NfGuessL gl = {0u, 0u, 0u, 0xffffffffu};
+    const NfLaneConst lc = nf_lane_const(lane);
+    const uint32_t group = a.core_guess == 1 ? kGuessGroup : 64u;  // blocks per trip
     int n_rounds = 0;
-    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_idle = 0, t_mark = 0, t_finish = 0; int n_groups = 0, n_restarts = 0; bool idling = false;)
+    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_idle = 0, t_mark = 0, t_finish = 0; int n_groups = 0, n_restarts = 0, n_trips = 0; bool idling = false; unsigned long long t_guess = 0, t_order = 0;)
     // blocks wave 0 may be ahead of wave 1: at least two groups (wave 1 waits for the whole group it is in), at most the ring
     // (as far as the ring reaches: the decay waves find a decay when wave 0 passes its start, and the further ahead of wave 1 that is,
     //  the more of the decay's chain -- 11-17 us -- is walked before wave 1 needs it: 768 -> 1920 blocks, 1.24 -> 1.17-1.19 ms per
@@ -1290,7 +1455,7 @@ __global__ __launch_bounds__(512) void k_tp_core2(const TpArgs a) {
     unsigned quit = share_peek(&sh->quit), rs = share_peek(&sh->rb_seq), w1_pos = share_peek(&sh->w1_pos),
              op_done = min(share_peek(&sh->fetch_next[0]), share_peek(&sh->fetch_next[1]));
     for (;;) {
-        const uint32_t n = min(64u, nblk - blk);
+        const uint32_t n = min(group, nblk - blk);
         const bool go = !quit && rs == ack && blk < nblk && blk + 64u <= w1_pos + lead && op_done >= blk + n;
         if (__builtin_expect(!go, 0)) {
             if (quit)
@@ -1300,7 +1465,7 @@ __global__ __launch_bounds__(512) void k_tp_core2(const TpArgs a) {
                 share_order();
                 blk = share_peek(&sh->rb_blk);
                 nf = *(lds_vf32*)&sh->rb_nf;
-                gs.dh = 0u;  // (the blocks before the restart point were not this chain's)
+                gs.dh = 0u, gl.key = 0xffffffffu;  // (the blocks before the restart point were not this chain's)
                 CORE_PROF(++n_restarts;)
                 ack = rs;
                 if (lane == 0)
@@ -1318,34 +1483,59 @@ __global__ __launch_bounds__(512) void k_tp_core2(const TpArgs a) {
             continue;
         }
         idle = 0;
-        CORE_PROF(if (idling) { idling = false; t_idle += prof_now() - t_mark; } ++n_groups;)
-        const float op = *(lds_vf32*)&sh->opring[(blk + lane) & (kOpRing - 1u)];
+        CORE_PROF(if (idling) { idling = false; t_idle += prof_now() - t_mark; })
+        float op = *(lds_vf32*)&sh->opring[(blk + lane) & (kOpRing - 1u)];
         // (the next trip's view of the other waves: in flight during the passes)
         const unsigned quit_n = *(const lds_vu32*)&sh->quit, rs_n = *(const lds_vu32*)&sh->rb_seq, w1_n = *(const lds_vu32*)&sh->w1_pos,
                        opd_n = *(const lds_vu32*)&sh->fetch_next[0], opd_n1 = *(const lds_vu32*)&sh->fetch_next[1];
-        // If every operand of the group lies above anything the chain can reach in 64 steps from here (it grows by less than
-        // 1e-6 (1 + 2^-23) + 2^-22 of itself per step while min() takes the chain value), min() is the identity throughout and
-        // the pass needs one instruction less: the same operations in the same order, bit for bit.
         float vnf;
-        if (a.core_guess && n == 64u) {
-            vnf = nf_chain_guess64(nf, op, gs, lane, n_rounds);
+        if (a.core_guess == 1 && n == kGuessGroup) {
+            // What a trip costs beside its rounds is two round trips to LDS -- the operands in, the results out before the mark -- and
+            // the bookkeeping above (0.4-0.5 us against 0.1-0.2 of rounds): up to four groups per trip, as far as the operands, the
+            // chunk and the lead reach; each group's operands are asked for while the group before is walked, the results wait for
+            // the mark once.
+            const uint32_t reach = min(min(op_done, nblk), w1_pos + lead - 1u) - blk;  // (>= 63 here)
+            const uint32_t ngr = reach >= 4u * kGuessGroup ? 4u : (reach >= 3u * kGuessGroup ? 3u : (reach >= 2u * kGuessGroup ? 2u : 1u));
+            for (uint32_t h = 0;;) {
+                const float op_next = *(lds_vf32*)&sh->opring[(blk + kGuessGroup + lane) & (kOpRing - 1u)];  // (unused after the last group)
+                CORE_PROF(const unsigned long long tg0 = prof_now();)
+                vnf = nf_chain_guess63(nf, op, gl, lc, lane, n_rounds);
+                CORE_PROF(t_guess += prof_now() - tg0;)
+                if (lane < static_cast<int>(kGuessGroup))
+                    *(lds_vf32*)&sh->nfring[(blk + lane) & (kNfRing - 1u)] = vnf;
+                blk += kGuessGroup;
+                CORE_PROF(++n_groups;)
+                if (++h >= ngr)
+                    break;
+                op = op_next;
+            }
         } else {
-            const bool above = n == 64u && __ballot(op >= nf * 1.0001f + 7e-5f) == ~0ull;
-            vnf = above ? nf_chain_self64(nf) : ((n == 64u) ? nf_chain_min64(nf, op) : nf_chain_min(nf, op, static_cast<int>(n)));
-            nf = rl(vnf, static_cast<int>(n) - 1);
-            gs.dh = 0u;
+            // If every operand of the group lies above anything the chain can reach in 64 steps from here (it grows by less than
+            // 1e-6 (1 + 2^-23) + 2^-22 of itself per step while min() takes the chain value), min() is the identity throughout and
+            // the pass needs one instruction less: the same operations in the same order, bit for bit.
+            if (a.core_guess && n == 64u) {
+                vnf = nf_chain_guess64(nf, op, gs, lane, n_rounds);
+            } else {
+                const bool above = n == 64u && __ballot(op >= nf * 1.0001f + 7e-5f) == ~0ull;
+                vnf = above ? nf_chain_self64(nf) : ((n == 64u) ? nf_chain_min64(nf, op) : nf_chain_min(nf, op, static_cast<int>(n)));
+                nf = rl(vnf, static_cast<int>(n) - 1);
+                gs.dh = 0u, gl.key = 0xffffffffu;
+            }
+            if (lane < static_cast<int>(n))
+                *(lds_vf32*)&sh->nfring[(blk + lane) & (kNfRing - 1u)] = vnf;
+            blk += n;
+            CORE_PROF(++n_groups;)
         }
-        if (lane < static_cast<int>(n))
-            *(lds_vf32*)&sh->nfring[(blk + lane) & (kNfRing - 1u)] = vnf;
+        CORE_PROF(const unsigned long long to0 = prof_now();)
         share_order();
+        CORE_PROF(t_order += prof_now() - to0; ++n_trips;)
         if (lane == 0)
-            share_post(&sh->w0_done, blk + n);
-        blk += n;
+            share_post(&sh->w0_done, blk);
         quit = __builtin_amdgcn_readfirstlane(quit_n), rs = __builtin_amdgcn_readfirstlane(rs_n);
         w1_pos = __builtin_amdgcn_readfirstlane(w1_n), op_done = min(__builtin_amdgcn_readfirstlane(opd_n), __builtin_amdgcn_readfirstlane(opd_n1));
     }
-    CORE_PROF(if (lane == 0 && r < 8) printf("core w0 row %d: finished after %llu us  idle before that %llu us  groups %d rounds %d restarts %d\n", r, (t_finish - t_begin) / 100, t_idle / 100, n_groups,
-                                           n_rounds, n_restarts);)
+    CORE_PROF(if (lane == 0 && r < 8) printf("core w0 row %d: finished after %llu us  idle before that %llu us  groups %d rounds %d restarts %d  trips %d  in the rounds %llu us  waiting for the results to land %llu us\n", r, (t_finish - t_begin) / 100, t_idle / 100, n_groups,
+                                           n_rounds, n_restarts, n_trips, t_guess / 100, t_order / 100);)
 }
 
 // Register budget of the lane kernels (k_tp_seg / k_tp_fix / k_tp_redo): waves per SIMD they are compiled for, 0 = whatever they take
