@@ -147,7 +147,7 @@ def run_workload(pkg, args, workload, steps, warmup, gather_mode, rank, world, l
     kms = {}  # kernel name -> [total ms, launches, steps whose timings were read]
 
     nstep = [0]
-    TIMING_AGE = 3
+    TIMING_AGE = int(os.environ.get("BENCH_TIMING_AGE", "4"))
     timed_hist = [False] * TIMING_AGE  # was the step one / two / three steps ago a timed one
 
     def add_times(times):

@@ -84,10 +84,11 @@ struct mi_demod {
     // passes of a call never touch what the tails of the two calls before it still read, so calls overlap (see enqueue()).
     // `cur` is the set of the last call; the serial path stays on it.
     int cur = 0;
-    // a call writes the set of the call four back: the host may then keep three calls queued behind the one whose timings it
-    // reads (mi_demod_kernel_time_prev, age 3) -- the tail of a call ends about one call after its core chain, and with only two
-    // queued the front of the next call started late every few calls
-    static constexpr int kSets = 4;
+    // a call writes the set of the call six back: the host may then keep four or five calls queued behind the one whose timings it
+    // reads (mi_demod_kernel_time_prev, age 4 or 5).  The tail of a call ends 2.8 ms after its core chain starts and stage 1 + the
+    // aggregates of a call need 0.85 ms before its own, so with the host reading at age 3 (four sets, rounds 2-3) the period could
+    // not fall below (2.8 + 0.85) / 3 = 1.2 ms -- which is what the step took once the chain itself was down to 1.03
+    static constexpr int kSets = 6;
     hipEvent_t ev[kSets][5] = {};  // per call: 0 begin, 1 stage 1 done, 2 call done, 3 serial k_demod begins (pipelined serial calls, mixed plans), 4 ... ends (mixed plans)
     static constexpr int kMaxChunks = 64, kEvPerChunk = 13, kSegStreams = 1;
     std::vector<hipEvent_t> chunk_ev[kSets];  // per chunk: stage1 begin/end, full end, core begin/end, seg begin/end, scan0/fix0/finish ends, rest begin

@@ -699,7 +699,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
     const uint32_t bps_log = 31u - static_cast<uint32_t>(__builtin_clz(bps));
 
     int n_run = 0, n_single = 0, n_step = 0, n_fail = 0;  // diagnostics: blocks per path, failed hypotheses
-    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_wait = 0, t_stepping = 0, t_mark = 0; int n_waits = 0, n_from_rec = 0, n_reclook = 0, n_fast4 = 0; unsigned long long t_recwait = 0;)
+    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_wait = 0, t_stepping = 0, t_mark = 0; int n_waits = 0, n_from_rec = 0, n_reclook = 0, n_fast4 = 0, n_capb = 0, n_sysr = 0, n_sysb = 0; unsigned long long t_recwait = 0, t_capb = 0, t_sysr = 0;)
     // kSplit: the noise-floor passes come from the chain wave (CoreShare).  `own`: this wave advanced the noise floor itself since it
     // last took a value from there (single blocks, decays): the next value taken is only good if the chain wave agrees on the one
     // before it.  `solo`: the chain wave was given up on (a wait ran out): from then on this wave walks the chain itself.
@@ -821,6 +821,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
             smp_ready = true;
         }
         int kk = 0;
+        bool skip_hyp = false;
         if (kSplit && nb == 64 && !solo && !own) {
             // ---- a whole group in one regime: the hypothesis path below with kk = 0 and all 64 lanes passing, as straight-line code
             // (that path is general and branchy: 0.55 us per group on a lone wave; this one is ~40 instructions).  Anything else --
@@ -854,7 +855,8 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                         ok = ok && c_entry < capj && cur.fm < capj;
                     else
                         ok = ok && capped_step(c_entry, cur.x0, capj) == capj && cur.xm >= capj;
-                    if (__ballot(ok) == ~0ull) {
+                    const unsigned long long okm = __ballot(ok);
+                    if (okm == ~0ull) {
                         if (boundary) {
                             TpCore t;
                             t.nf = nf_prev, t.cap = cap_prev, t.c = c_entry, t.full = full_entry;
@@ -869,6 +871,26 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                         fe_group = full;
                         continue;
                     }
+                    // The leading run of blocks that pass is what the general path below would accept from kk = 0 (the same checks on
+                    // the same values), and the block behind it is one the hypothesis fails on: take the run here and send that block
+                    // straight to the stepping code instead of judging the group a second time (64 regime changes per channel-minute).
+                    const int nacc = trailing_ones_from(okm, 0);
+                    if (nacc > 0) {
+                        if (boundary && lane < nacc) {
+                            TpCore t;
+                            t.nf = nf_prev, t.cap = cap_prev, t.c = c_entry, t.full = full_entry;
+                            core[(g0 + lane) >> bps_log] = t;
+                        }
+                        nf = rl(vnf, nacc - 1);
+                        cap = cap_of(p, nf);
+                        full = rl(cur.fe, nacc - 1);
+                        c = merged ? full : cap;
+                        kk = nacc;
+                        n_run += nacc;
+                        ++n_single;
+                    }
+                    ++n_fail;
+                    skip_hyp = true;
                 }
             }
         }
@@ -877,7 +899,9 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
             nf = uni(nf), cap = uni(cap), c = uni(c), full = uni(full);
             if (kSplit && lane == 0)
                 share_post(&sh->w1_pos, g0 + kk);
-            if (c == full || c == cap) {
+            const bool judged = skip_hyp;  // (block kk has just failed the hypothesis in the whole-group path above)
+            skip_hyp = false;
+            if (!judged && (c == full || c == cap)) {
                 // Hypothesis: the regime of the current block persists.  The noise-floor chain is walked serially
                 // (the only true dependence), every block's precondition is then checked by its own lane.
                 const bool merged = (c == full);
@@ -1082,6 +1106,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                                     }
                                 }
                             }
+                            CORE_PROF(++n_sysr; const unsigned long long t_s0 = prof_now();)
                             if (kSplit && ring_ok) {
                                 float em1 = 0.0f;
                                 if (lane > kk) {
@@ -1113,6 +1138,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                                 }
                             }
                             const int nacc = min(min(trailing_ones_from(__ballot(ok), kk + 1), kRound), nb - 1 - kk);
+                            CORE_PROF(t_sysr += prof_now() - t_s0; n_sysb += nacc;)
                             if (nacc == 0)
                                 break;
                             if (boundary && lane > kk && lane <= kk + nacc) {
@@ -1131,6 +1157,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                         }
                         fe = fe_k;
                     } else {
+                        CORE_PROF(++n_capb; const unsigned long long t_c0 = prof_now();)
                         // capped_step() with the shortcut "c >= cap && x >= cap" as "c >= t", t = cap where x >= cap, +inf elsewhere
                         const float xs[16] = {rl(smp.s0.x, kk), rl(smp.s0.y, kk), rl(smp.s0.z, kk), rl(smp.s0.w, kk), rl(smp.s1.x, kk), rl(smp.s1.y, kk),
                                               rl(smp.s1.z, kk), rl(smp.s1.w, kk), rl(smp.s2.x, kk), rl(smp.s2.y, kk), rl(smp.s2.z, kk), rl(smp.s2.w, kk),
@@ -1142,6 +1169,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                             const float m = (e < cap) ? e : cap;
                             c = (c >= t) ? cap : m;
                         }
+                        CORE_PROF(t_capb += prof_now() - t_c0;)
                     }
                     full = fe;
                 } else {
@@ -1160,8 +1188,8 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
         }
         fe_group = rl(cur.fe, 63);
     }
-    CORE_PROF(if (lane == 0 && r < 8) printf("core w1 row %d: total %llu us  wait-w0 %llu us (%d waits)  stepping %llu us (record waits %llu us, %d looks)  run %d accepted-runs %d step %d (from records %d) fail %d rollback %d solo %d fast4 %d\n", r,
-                                           (prof_now() - t_begin) / 100, t_wait / 100, n_waits, t_stepping / 100, t_recwait / 100, n_reclook, n_run, n_single, n_step, n_from_rec, n_fail, n_rollback, (int)solo, n_fast4);)
+    CORE_PROF(if (lane == 0 && r < 8) printf("core w1 row %d: total %llu us  wait-w0 %llu us (%d waits)  stepping %llu us (record waits %llu us, %d looks)  run %d accepted-runs %d step %d (from records %d) fail %d rollback %d solo %d fast4 %d; cap-binding blocks %d in %llu us, systolic rounds %d (%d blocks) in %llu us\n", r,
+                                           (prof_now() - t_begin) / 100, t_wait / 100, n_waits, t_stepping / 100, t_recwait / 100, n_reclook, n_run, n_single, n_step, n_from_rec, n_fail, n_rollback, (int)solo, n_fast4, n_capb, t_capb / 100, n_sysr, n_sysb, t_sysr / 100);)
     if (kSplit && lane == 0)
         share_post(&sh->quit, 1u);
     if (lane == 0) {
@@ -1495,6 +1523,7 @@ __global__ __launch_bounds__(512) void k_tp_core2(const TpArgs a) {
             // chunk and the lead reach; each group's operands are asked for while the group before is walked, the results wait for
             // the mark once.
             const uint32_t reach = min(min(op_done, nblk), w1_pos + lead - 1u) - blk;  // (>= 63 here)
+            // (eight per trip: no better; one per trip while the walking wave is right behind: no better either)
             const uint32_t ngr = reach >= 4u * kGuessGroup ? 4u : (reach >= 3u * kGuessGroup ? 3u : (reach >= 2u * kGuessGroup ? 2u : 1u));
             for (uint32_t h = 0;;) {
                 const float op_next = *(lds_vf32*)&sh->opring[(blk + kGuessGroup + lane) & (kOpRing - 1u)];  // (unused after the last group)

@@ -34,14 +34,22 @@ h.process_device(d_iq.data_ptr(), nbytes, nbat, wo[0].data_ptr(), ax[0].data_ptr
 base = d_iq.data_ptr() + AGC_EXTRA * HOP * 2
 cols = [("s1", 0, 1), ("full", 11, 2), ("core", 3, 4), ("seg", 5, 12), ("scan", 10, 7), ("fix+redo", 7, 8), ("rest", 8, 9)]
 rows, t_abs = [], 0.0
+late = bool(os.environ.get("LATE_READ"))  # no reads while the calls are submitted: the last four calls' events after the loop
 for k in range(ncalls):
     h.process_device(base, nbytes, nbat, wo[k % 3].data_ptr(), ax[k % 3].data_ptr(), hip_stream=st.cuda_stream)
-    if k >= 3:  # the call three back, relative to its own core start; and the start of the next core after it
+    if k >= 3 and not late:  # the call three back, relative to its own core start; and the start of the next core after it
         ev = [(h.event_ms(3, 3, 0, a), h.event_ms(3, 3, 0, b)) for _, a, b in cols]
         nxt = h.event_ms(3, 2, 0, 3)
         rows.append((k - 3, t_abs, ev))
         t_abs += nxt if nxt is not None else 0.0
 torch.cuda.synchronize()
+if late:
+    print("ms relative to the core start of the call three before the last (no event reads during the run):   " + "   ".join(f"{n:>13s}" for n, _, _ in cols))
+    for age in (3, 2, 1, 0):
+        ev = [(h.event_ms(3, age, 0, a), h.event_ms(3, age, 0, b)) for _, a, b in cols]
+        print(f"call last-{age}:           " + "   ".join("      -      " if a is None or b is None else f"{a:6.2f}-{b:6.2f}" for a, b in ev))
+    h.close()
+    sys.exit(0)
 print("absolute ms (core start of call 3 = 0):   " + "   ".join(f"{n:>13s}" for n, _, _ in cols))
 for k, t0, ev in rows[4:]:
     print(f"call {k:3d} core starts {t0:7.2f}:           " + "   ".join("      -      " if a is None else f"{t0 + a:6.2f}-{t0 + b:6.2f}" for a, b in ev))
