@@ -227,9 +227,10 @@ int mi_demod_last_kernel_ms(mi_demod* h, float* channelize_ms, float* demod_ms);
  * sum over those launches (kernels of different chunks and calls overlap on several streams, so the sums exceed the wall time).
  * Returns MI_ERR_INVALID past the last index: iterate from 0 until it fails.  *name is a static string. */
 int mi_demod_kernel_time(mi_demod* h, int index, const char** name, float* ms_total, int* launches);
-/* The same for an earlier call: age 1 = the call before the last one, age 2, 3 = the ones before that (while the event set has
- * not been reused; serial calls reuse the set of the call before them).  Lets a caller that keeps calls in flight read the
- * timings of call k after it has enqueued calls k+1, k+2, without draining the pipeline. */
+/* The same for an earlier call: age 1 = the call before the last one, age 2 .. 5 = the ones before that (while the event set has
+ * not been reused: six sets cycle; serial calls reuse the set of the call before them).  Lets a caller that keeps calls in flight
+ * read the timings of call k after it has enqueued calls k+1 .. k+4, without draining the pipeline (reading them earlier makes the
+ * host wait for the end of call k's tail and the front of the following calls start late: DESIGN.md section 6). */
 int mi_demod_kernel_time_prev(mi_demod* h, int age, int index, const char** name, float* ms_total, int* launches);
 /* (diagnostic) Where a launch of a time-parallel call sat in time: milliseconds from the start of the core chain of the call
  * `ref_age` calls back to event `event` of chunk `chunk` of the call `age` calls back (events per chunk: 0 / 1 stage 1 begin / end,

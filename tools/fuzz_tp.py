@@ -100,5 +100,7 @@ for seed in range(first, last):
     same = same and np.array_equal(wo_d, wo_b) and np.array_equal(np.concatenate([r0[1], r1[1]], axis=2), ax_b) and bytes(r1[3]) == st_b
     if not same:
         bad += 1
-        print("seed", seed, "MISMATCH (path", path, ")")
+        print("seed", seed, "MISMATCH (path", path, ")", flush=True)
+    if seed % 100 == 99:
+        print("... seed", seed, "failures so far:", bad, flush=True)
 print("tp fuzz done, failures:", bad)
