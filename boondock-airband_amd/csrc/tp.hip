@@ -699,7 +699,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
     const uint32_t bps_log = 31u - static_cast<uint32_t>(__builtin_clz(bps));
 
     int n_run = 0, n_single = 0, n_step = 0, n_fail = 0;  // diagnostics: blocks per path, failed hypotheses
-    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_wait = 0, t_stepping = 0, t_mark = 0; int n_waits = 0, n_from_rec = 0, n_reclook = 0, n_fast4 = 0, n_capb = 0, n_sysr = 0, n_sysb = 0; unsigned long long t_recwait = 0, t_capb = 0, t_sysr = 0;)
+    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_wait = 0, t_stepping = 0, t_mark = 0; int n_waits = 0, n_from_rec = 0, n_reclook = 0, n_fast4 = 0, n_capb = 0, n_sysr = 0, n_sysb = 0, n_f1 = 0, n_gen = 0; unsigned long long t_recwait = 0, t_capb = 0, t_sysr = 0, t_f4 = 0, t_f1 = 0, t_gen = 0;)
     // kSplit: the noise-floor passes come from the chain wave (CoreShare).  `own`: this wave advanced the noise floor itself since it
     // last took a value from there (single blocks, decays): the next value taken is only good if the chain wave agrees on the one
     // before it.  `solo`: the chain wave was given up on (a wait ran out): from then on this wave walks the chain itself.
@@ -715,6 +715,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
     }
     uint32_t fetch_seen = a.blk0;  // kSplit: blocks whose aggregates the fetch waves are known to have delivered
     for (uint32_t g0 = a.blk0; g0 < nblk; g0 += 64) {
+        CORE_PROF(const unsigned long long t_it0 = prof_now();)
         if (kSplit && !solo && !own && g0 + 256u <= nblk) {
             // ---- four groups in one regime at once.  Under the hypothesis that the regime persists every block's check depends on ring
             // values alone (the state entering a block is the noise floor the chain wave left for the block before, full_ at its
@@ -776,7 +777,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                         c = merged ? full : cap;
                         n_run += 256;
                         ++n_single;
-                        CORE_PROF(++n_fast4;)
+                        CORE_PROF(++n_fast4; t_f4 += prof_now() - t_it0;)
                         fe_group = full;
                         g0 += 192u;
                         continue;
@@ -869,6 +870,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
                         n_run += 64;
                         ++n_single;
                         fe_group = full;
+                        CORE_PROF(++n_f1; t_f1 += prof_now() - t_it0;)
                         continue;
                     }
                     // The leading run of blocks that pass is what the general path below would accept from kk = 0 (the same checks on
@@ -1187,7 +1189,9 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
             CORE_PROF(t_stepping += prof_now() - t_step0;)
         }
         fe_group = rl(cur.fe, 63);
+        CORE_PROF(++n_gen; t_gen += prof_now() - t_it0;)
     }
+    CORE_PROF(if (lane == 0 && r < 8) printf("core w1 row %d: groups by path: four at once %d in %llu us, whole group %d in %llu us, general %d in %llu us (stepping included)\n", r, n_fast4, t_f4 / 100, n_f1, t_f1 / 100, n_gen, t_gen / 100);)
     CORE_PROF(if (lane == 0 && r < 8) printf("core w1 row %d: total %llu us  wait-w0 %llu us (%d waits)  stepping %llu us (record waits %llu us, %d looks)  run %d accepted-runs %d step %d (from records %d) fail %d rollback %d solo %d fast4 %d; cap-binding blocks %d in %llu us, systolic rounds %d (%d blocks) in %llu us\n", r,
                                            (prof_now() - t_begin) / 100, t_wait / 100, n_waits, t_stepping / 100, t_recwait / 100, n_reclook, n_run, n_single, n_step, n_from_rec, n_fail, n_rollback, (int)solo, n_fast4, n_capb, t_capb / 100, n_sysr, n_sysb, t_sysr / 100);)
     if (kSplit && lane == 0)

@@ -66,5 +66,7 @@ for seed in range(first, last):
             same = same and np.array_equal(zo[0, c].reshape(-1), oiq[c])
     if not same:
         bad += 1
-        print("seed", seed, "MISMATCH")
+        print("seed", seed, "MISMATCH", flush=True)
+    if seed % 50 == 49:
+        print("... seed", seed, "failures so far:", bad, flush=True)
 print("oracle fuzz done, failures:", bad)
