@@ -296,14 +296,18 @@ def test_time_parallel_hard_signals(pkg, monkeypatch):
     assert max(s.flappy_count for s in st) > 0, "the input was meant to trigger flap detection"
 
 
-def test_time_parallel_core_chain_exact_and_no_fallback(pkg, monkeypatch):
+@pytest.mark.parametrize("noise_floor_walk", ["1", "2", "0"], ids=["rounds-of-63", "rounds-of-64", "systolic-passes"])
+def test_time_parallel_core_chain_exact_and_no_fallback(pkg, monkeypatch, noise_floor_walk):
     """The exact Squelch core state (noise floor, cap, capped, full) the time-parallel path computes at every
     512-step boundary equals the oracle's serial values, and the gated-carrier workload needs no serial
-    fallback: only the segments holding an opening edge are re-run (scan 0), then everything verifies."""
+    fallback: only the segments holding an opening edge are re-run (scan 0), then everything verifies.
+    Once for each way the chain's noise-floor wave can walk (MI_AIRBAND_CORE_GUESS: the guess-and-verify rounds on groups of
+    63 blocks that the product runs, the first rounds on groups of 64, the plain systolic passes)."""
     import ctypes as C
     import libs
     from common import to_oracle_cfg
     monkeypatch.setenv("MI_AIRBAND_TP", "1")
+    monkeypatch.setenv("MI_AIRBAND_CORE_GUESS", noise_floor_walk)
     centre, chans = pkg.config2_channels()
     chans[1] = pkg.channel_cfg(chans[1].freq, squelch_threshold_dbfs=-30)  # manual level: constant cap
     chans[3] = pkg.channel_cfg(chans[3].freq, squelch_snr_db=1.0)
