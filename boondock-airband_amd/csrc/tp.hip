@@ -474,16 +474,17 @@ __device__ __forceinline__ float nf_chain_guess63(float& nf, const float op, NfG
             "v_readlane_b32 %[nfb], v121, %[last]\n"
             "s_cbranch_scc1 2f\n"                       // the group is done
             "v_readlane_b32 %[dl], v122, %[last]\n"
-            "v_cmp_lt_f32 vcc, %[op], v120\n"
             "s_add_i32 %[early], %[early], 1\n"
             "s_sub_i32 s20, %[dl], %[incm1]\n"
             "s_cmp_le_u32 s20, 2\n"
             "s_cbranch_scc1 4f\n"                       // an exception the pattern did not have
-            "6:\n"
+            "v_cmp_lt_f32 vcc, %[op], v120\n"          // a step below the floor: is the block behind it one as well (judged by its guess)?
             "s_bitcmp1_b64 vcc, %[kk]\n"
             "s_cbranch_scc1 5f\n"                       // a run below the floor
+            "6:\n"
             "s_cmp_ge_u32 %[early], 8\n"
-            "s_cbranch_scc0 1b\n"                       // a lone step below the floor: the next round
+            "s_cbranch_scc0 1b\n"                       // a lone step below the floor / a lone exception: the next round
+            "v_cmp_lt_f32 vcc, %[op], v120\n"
             "5:\n"
             "s_lshr_b64 s[20:21], vcc, %[kk]\n"
             "s_not_b64 s[20:21], s[20:21]\n"
@@ -1473,12 +1474,13 @@ __global__ __launch_bounds__(512) void k_tp_core2(const TpArgs a) {
     float nf = a.core_carry[r].nf;
     uint32_t blk = a.blk0;
     unsigned ack = 0, idle = 0;
+    bool unmarked = false;  // the results of the last trip are in the ring, w0_done does not say so yet
     NfGuess gs = {0u};
     NfGuessL gl = {0u, 0u, 0u, 0xffffffffu};
     const NfLaneConst lc = nf_lane_const(lane);
     const uint32_t group = a.core_guess == 1 ? kGuessGroup : 64u;  // blocks per trip
     int n_rounds = 0;
-    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_idle = 0, t_mark = 0, t_finish = 0; int n_groups = 0, n_restarts = 0, n_trips = 0; bool idling = false; unsigned long long t_guess = 0, t_order = 0;)
+    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_idle = 0, t_mark = 0, t_finish = 0; int n_groups = 0, n_restarts = 0, n_trips = 0; bool idling = false; unsigned long long t_guess = 0;)
     // blocks wave 0 may be ahead of wave 1: at least two groups (wave 1 waits for the whole group it is in), at most the ring
     // (as far as the ring reaches: the decay waves find a decay when wave 0 passes its start, and the further ahead of wave 1 that is,
     //  the more of the decay's chain -- 11-17 us -- is walked before wave 1 needs it: 768 -> 1920 blocks, 1.24 -> 1.17-1.19 ms per
@@ -1492,6 +1494,12 @@ __global__ __launch_bounds__(512) void k_tp_core2(const TpArgs a) {
         if (__builtin_expect(!go, 0)) {
             if (quit)
                 break;
+            if (unmarked) {  // (nothing follows at once: the last trip's mark now)
+                share_order();
+                if (lane == 0)
+                    share_post(&sh->w0_done, blk);
+                unmarked = false;
+            }
             CORE_PROF(if (!idling) { idling = true; t_mark = prof_now(); if (blk >= nblk && !t_finish) t_finish = t_mark; })
             if (rs != ack) {  // wave 1 disagrees from block rb_blk on: start again there with its noise floor
                 share_order();
@@ -1520,6 +1528,14 @@ __global__ __launch_bounds__(512) void k_tp_core2(const TpArgs a) {
         // (the next trip's view of the other waves: in flight during the passes)
         const unsigned quit_n = *(const lds_vu32*)&sh->quit, rs_n = *(const lds_vu32*)&sh->rb_seq, w1_n = *(const lds_vu32*)&sh->w1_pos,
                        opd_n = *(const lds_vu32*)&sh->fetch_next[0], opd_n1 = *(const lds_vu32*)&sh->fetch_next[1];
+        // The mark for the trip before this one: its results have long landed, and the wait for them is the wait for this trip's
+        // operands, which the first round needs anyway (at the end of the trip it was a round trip to LDS of its own).
+        if (unmarked) {
+            share_order();
+            if (lane == 0)
+                share_post(&sh->w0_done, blk);
+            unmarked = false;
+        }
         float vnf;
         if (a.core_guess == 1 && n == kGuessGroup) {
             // What a trip costs beside its rounds is two round trips to LDS -- the operands in, the results out before the mark -- and
@@ -1559,16 +1575,13 @@ __global__ __launch_bounds__(512) void k_tp_core2(const TpArgs a) {
             blk += n;
             CORE_PROF(++n_groups;)
         }
-        CORE_PROF(const unsigned long long to0 = prof_now();)
-        share_order();
-        CORE_PROF(t_order += prof_now() - to0; ++n_trips;)
-        if (lane == 0)
-            share_post(&sh->w0_done, blk);
+        unmarked = true;
+        CORE_PROF(++n_trips;)
         quit = __builtin_amdgcn_readfirstlane(quit_n), rs = __builtin_amdgcn_readfirstlane(rs_n);
         w1_pos = __builtin_amdgcn_readfirstlane(w1_n), op_done = min(__builtin_amdgcn_readfirstlane(opd_n), __builtin_amdgcn_readfirstlane(opd_n1));
     }
-    CORE_PROF(if (lane == 0 && r < 8) printf("core w0 row %d: finished after %llu us  idle before that %llu us  groups %d rounds %d restarts %d  trips %d  in the rounds %llu us  waiting for the results to land %llu us\n", r, (t_finish - t_begin) / 100, t_idle / 100, n_groups,
-                                           n_rounds, n_restarts, n_trips, t_guess / 100, t_order / 100);)
+    CORE_PROF(if (lane == 0 && r < 8) printf("core w0 row %d: finished after %llu us  idle before that %llu us  groups %d rounds %d restarts %d  trips %d  in the rounds %llu us\n", r, (t_finish - t_begin) / 100, t_idle / 100, n_groups,
+                                           n_rounds, n_restarts, n_trips, t_guess / 100);)
 }
 
 // Register budget of the lane kernels (k_tp_seg / k_tp_fix / k_tp_redo): waves per SIMD they are compiled for, 0 = whatever they take
