@@ -110,7 +110,9 @@ def run_workload(pkg, args, workload, steps, warmup, gather_mode, rank, world, l
     # ones and would synchronise with the NULL stream
     # (only where those streams are used -- plans of up to 64 rows on the time-parallel path: elsewhere a second user stream only takes a
     # hardware queue away from the library's own, BENCH_STREAM=null|side forces one)
-    want_side = {"null": False, "side": True}.get(os.environ.get("BENCH_STREAM", ""), nstreams * nch <= 64 and workload in ("config2", "am64"))
+    # (... and plans of 449 .. 512 rows on the serial kernel, whose stage 1 and k_demod take disjoint CUs: MI_OPT_SPLIT_CUS)
+    want_side = {"null": False, "side": True}.get(os.environ.get("BENCH_STREAM", ""),
+                                                  (nstreams * nch <= 64 and workload in ("config2", "am64")) or (workload == "am64" and 448 < nstreams * nch <= 512))
     stream = torch.cuda.Stream() if want_side else torch.cuda.current_stream()
     torch.cuda.set_stream(stream)
 

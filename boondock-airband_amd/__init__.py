@@ -47,6 +47,7 @@ OPT_RESERVE_CUS = 15
 OPT_PRE_WAVE = 14
 OPT_AUDIO_WAVE = 16
 OPT_MIXED_PLAN = 17
+OPT_SPLIT_CUS = 18
 SFMT_U8, SFMT_S8, SFMT_S16, SFMT_F32 = 1, 2, 3, 4
 
 MI_OK, MI_ERR_INVALID, MI_ERR_NO_DEVICE, MI_ERR_NOMEM, MI_ERR_HIP, MI_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5

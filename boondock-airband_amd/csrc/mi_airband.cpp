@@ -133,6 +133,11 @@ struct mi_demod {
     hipStream_t front_stream_m = nullptr;
     hipStream_t seg_stream_m[kSegStreams] = {nullptr};
     int opt_reserve_cus = -1;  // -1 auto: 32 for handles of up to 64 rows, none beyond; 0 none
+    // MI_OPT_SPLIT_CUS: pipelined serial calls: stage 1 keeps off the last n CUs, k_demod runs on them alone; -1 auto (see enqueue)
+    int opt_split_cus = -1;
+    int split_state = 0;  // 0 undecided, 1 the two CU-masked streams exist, 2 none
+    hipStream_t ps_front_m = nullptr, ps_demod_m = nullptr;
+    hipEvent_t ev_ps_entry = nullptr, ev_ps_done = nullptr;
     int last_masked = -1;      // which side the previous time-parallel call used
     int masked_state = 0;      // 0 undecided, 1 the masked twins carry the time-parallel passes of this handle, 2 the plain streams do
     int tp_chunks[kSets] = {};
@@ -295,6 +300,8 @@ void tuning_from_env(mi_demod* h) {
         h->opt_core_lead = std::max(0, std::atoi(e));
     if (const char* e = get("MI_AIRBAND_RESERVE_CUS"))
         h->opt_reserve_cus = std::max(-1, std::atoi(e));
+    if (const char* e = get("MI_AIRBAND_SPLIT_CUS"))
+        h->opt_split_cus = std::max(-1, std::atoi(e));
     if (const char* e = get("MI_AIRBAND_AGC_HINT"))
         h->opt_agc_hint = std::atoi(e) != 0;
     if (const char* e = get("MI_AIRBAND_CORE_DECAY"))
@@ -881,7 +888,35 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         const int before_prev = (h->cur + mi_demod::kSets - 1) % mi_demod::kSets;
         const int p = h->pset, np = p ^ 1;
         evc = h->ev[q];
-        hipStream_t fs = h->front_stream;
+        if (h->split_state == 0) {
+            h->split_state = 2;
+            hipDeviceProp_t prop{};
+            // Two waves per row (k_demod_pw2) of 449 .. 512 rows fill 128 CUs two to a SIMD -- the kernel's pace alone -- and stage 1 of
+            // that many streams takes as long on the other 128 as the kernel does: side by side on disjoint CUs 3.47 ms per 8-s call of
+            // 64 x 8 AM channels, sharing every SIMD 3.8 (stage 1 3.4-3.5 ms beside the kernel's waves against 1.9 alone).  With fewer
+            // rows the call is the kernel's latency either way and the split only takes CUs from stage 1 (tools/split_rows.sh); with
+            // more the kernel needs more than 128 CUs (112 for 512 rows: 3.7 ms).
+            const int want = h->opt_split_cus >= 0 ? h->opt_split_cus : ((da.pre_wave == 2 && h->rows > 448 && h->rows <= 512) ? 128 : 0);
+            if (want > 0 && hipGetDeviceProperties(&prop, h->gpu) == hipSuccess && prop.multiProcessorCount >= want + 32) {
+                const int ncu = prop.multiProcessorCount, keep = ncu - want;
+                std::vector<uint32_t> m_front(static_cast<size_t>((ncu + 31) / 32), 0u), m_demod(m_front.size(), 0u);
+                for (int i = 0; i < ncu; ++i)
+                    (i < keep ? m_front : m_demod)[static_cast<size_t>(i) / 32] |= 1u << (i % 32);
+                hipError_t me = hipExtStreamCreateWithCUMask(&h->ps_front_m, static_cast<uint32_t>(m_front.size()), m_front.data());
+                if (me == hipSuccess)
+                    me = hipExtStreamCreateWithCUMask(&h->ps_demod_m, static_cast<uint32_t>(m_demod.size()), m_demod.data());
+                if (me == hipSuccess)
+                    me = hipEventCreateWithFlags(&h->ev_ps_entry, hipEventDisableTiming);
+                if (me == hipSuccess)
+                    me = hipEventCreateWithFlags(&h->ev_ps_done, hipEventDisableTiming);
+                if (me == hipSuccess)
+                    h->split_state = 1;
+                else
+                    (void)hipGetLastError();
+            }
+        }
+        const bool split = h->split_state == 1 && s != nullptr;
+        hipStream_t fs = split ? h->ps_front_m : h->front_stream;
         if (iq_ready)
             HIP_TRY(hipStreamWaitEvent(fs, iq_ready, 0));
         if (h->serial_pipe && h->set_seq[before_prev])  // the call before the previous one read the body of set p
@@ -893,13 +928,24 @@ int enqueue(mi_demod* h, const unsigned char* d_iq, size_t stream_stride, size_t
         HIP_TRY(hipEventRecord(evc[0], fs));
         HIP_TRY(stage1_launch(ca, 0, fs));
         HIP_TRY(hipEventRecord(evc[1], fs));
-        HIP_TRY(hipStreamWaitEvent(s, evc[1], 0));
         da.mag = h->d_mag_set[p];
         da.cplx = h->d_cplx_set[p];
         da.mag_head = h->d_mag_set[np];
         da.cplx_head = h->d_cplx_set[np];
-        HIP_TRY(hipEventRecord(evc[3], s));
-        HIP_TRY(mi::launch_demod(da, s));
+        if (split) {  // k_demod on the CUs stage 1 keeps off, in the caller's stream order all the same
+            hipStream_t ds = h->ps_demod_m;
+            HIP_TRY(hipEventRecord(h->ev_ps_entry, s));
+            HIP_TRY(hipStreamWaitEvent(ds, h->ev_ps_entry, 0));
+            HIP_TRY(hipStreamWaitEvent(ds, evc[1], 0));
+            HIP_TRY(hipEventRecord(evc[3], ds));
+            HIP_TRY(mi::launch_demod(da, ds));
+            HIP_TRY(hipEventRecord(h->ev_ps_done, ds));
+            HIP_TRY(hipStreamWaitEvent(s, h->ev_ps_done, 0));
+        } else {
+            HIP_TRY(hipStreamWaitEvent(s, evc[1], 0));
+            HIP_TRY(hipEventRecord(evc[3], s));
+            HIP_TRY(mi::launch_demod(da, s));
+        }
         h->chain_live = false;
         h->cur = q;
         h->pset = np;
@@ -1003,6 +1049,14 @@ void mi_demod_destroy(mi_demod* h) {
             (void)hipEventDestroy(e);
     if (h->front_stream_m)
         (void)hipStreamDestroy(h->front_stream_m);
+    if (h->ps_front_m)
+        (void)hipStreamDestroy(h->ps_front_m);
+    if (h->ps_demod_m)
+        (void)hipStreamDestroy(h->ps_demod_m);
+    if (h->ev_ps_entry)
+        (void)hipEventDestroy(h->ev_ps_entry);
+    if (h->ev_ps_done)
+        (void)hipEventDestroy(h->ev_ps_done);
     for (hipStream_t ss : h->seg_stream_m)
         if (ss)
             (void)hipStreamDestroy(ss);
@@ -1989,6 +2043,11 @@ int mi_demod_set_option(mi_demod* h, int option, int value) {
             return MI_OK;
         case MI_OPT_MIXED_PLAN:
             h->opt_mixed = value != 0;
+            return MI_OK;
+        case MI_OPT_SPLIT_CUS:
+            if (h->split_state != 0)
+                return fail(MI_ERR_INVALID, "MI_OPT_SPLIT_CUS is decided at the handle's first overlapped serial call: set it before");
+            h->opt_split_cus = value < 0 ? -1 : value;
             return MI_OK;
         default:
             return fail(MI_ERR_INVALID, "unknown option");

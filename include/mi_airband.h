@@ -286,6 +286,12 @@ enum {
                                * plain AM rows down the time-parallel path and the rest through the serial kernel, side by side in the same
                                * call (by itself in calls of >= 64 batches -- the time-parallel half has a fixed latency --, in any call under
                                * MI_OPT_TIME_PARALLEL = 1); 0: such a plan takes the serial kernel for every row */
+    MI_OPT_SPLIT_CUS = 18,    /* Calls that take the serial kernel and overlap (MI_OPT_EARLY_INPUT): n > 0: k_demod runs alone on the last n CUs and
+                               * stage 1 of the next call on the others (two CU-restricted streams, as under MI_OPT_RESERVE_CUS: only for calls whose
+                               * stream is not the NULL stream); 0: the two share every CU; -1 (default): 128 for plans of 449 .. 512 rows -- two waves
+                               * per row then fill 128 CUs two to a SIMD and stage 1 of as many streams is as long as the serial kernel: 64 streams x 8
+                               * AM channels 344 -> 378 GS/s; with fewer rows the call is the serial kernel's latency either way.
+                               * Set before the handle's first such call. */
     MI_OPT_LANE_FFT_JIT = 11  /* 1 (default): that kernel is compiled for the plan's own FFT nodes by hipRTC on first use (the code object is
                                * cached per (device, hop, masks) for the life of the process); 0, or hipRTC missing: the prebuilt full graph */
 };

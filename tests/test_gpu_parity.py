@@ -522,6 +522,52 @@ def test_consecutive_calls_overlap_with_early_input(pkg, monkeypatch, calls):
         assert_same(wo[0], owo, f"audio ({streams} stream)")
 
 
+@pytest.mark.parametrize("split_cus", [128, 64, 0])
+def test_overlapped_serial_calls_on_disjoint_cus_keep_every_bit(pkg, monkeypatch, split_cus):
+    """MI_OPT_SPLIT_CUS: overlapped calls on the serial kernel with k_demod alone on the last n CUs and stage 1 of the next call on the
+    others (two CU-restricted streams), on a stream of the caller's and -- where the split does not apply -- on the NULL stream, calls
+    of different lengths back to back without a host synchronisation: audio and flags are the oracle's."""
+    import torch
+    monkeypatch.setenv("MI_AIRBAND_TP", "0")  # every call on the serial kernel
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    calls = [8, 16, 3, 8, 12]
+    nbat = sum(calls)
+    iq, _ = gen_iq(pkg, dev, centre, chans, nbat, gate_div=3)
+    nb, owo, oaxc, _ = oracle_run(dev, chans, iq, nbat)
+    assert nb == nbat
+    pad = (iq.size + 255) // 256 * 256
+    d_iq = torch.zeros(pad, dtype=torch.uint8, device="cuda")
+    d_iq[:iq.size] = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for streams in ("side", "null", "both"):
+        d = pkg.Demod(dev, chans, nstreams=1, max_batches=max(calls))
+        d.set_option(pkg.OPT_EARLY_INPUT, 1)
+        d.set_option(pkg.OPT_SPLIT_CUS, split_cus)
+        outs, flags, done = [], [], 0
+        for n, k in enumerate(calls):
+            pos = 0 if done == 0 else (done * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+            wo = torch.empty((1, len(chans), k * WAVE_BATCH), dtype=torch.float32, device="cuda")
+            ax = torch.empty((1, len(chans), k), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            use_side = streams == "side" or (streams == "both" and n % 2 == 1)
+            s = side.cuda_stream if use_side else torch.cuda.current_stream().cuda_stream
+            d.process_device(d_iq.data_ptr() + pos, pad - pos, k, wo.data_ptr(), ax.data_ptr(), hip_stream=s)
+            assert d.last_path()[0] == 0
+            if streams == "both":
+                torch.cuda.synchronize()  # calls on different caller streams are the caller's to order
+            outs.append(wo)
+            flags.append(ax)
+            done += k
+        torch.cuda.synchronize()
+        wo = torch.cat(outs, dim=2).cpu().numpy()
+        ax = torch.cat(flags, dim=2).cpu().numpy()
+        d.close()
+        assert_same(ax[0], oaxc, f"axcindicate ({streams} stream, {split_cus} CUs)")
+        assert_same(wo[0], owo, f"audio ({streams} stream, {split_cus} CUs)")
+
+
 @pytest.mark.parametrize("spec_head,core_split,seg", [(1, 1, 512), (0, 1, 512), (1, 0, 512), (0, 0, 512), (1, 1, 2048), (1, 1, 4096)])
 def test_overlapped_calls_speculative_head_and_split_chain_keep_every_bit(pkg, monkeypatch, spec_head, core_split, seg):
     """Overlapped calls with alternating audio buffers: the first segments of a call warm up on the previous call's planes from a
