@@ -700,7 +700,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
     const uint32_t bps_log = 31u - static_cast<uint32_t>(__builtin_clz(bps));
 
     int n_run = 0, n_single = 0, n_step = 0, n_fail = 0;  // diagnostics: blocks per path, failed hypotheses
-    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_wait = 0, t_stepping = 0, t_mark = 0; int n_waits = 0, n_from_rec = 0, n_reclook = 0, n_fast4 = 0, n_capb = 0, n_sysr = 0, n_sysb = 0, n_f1 = 0, n_gen = 0; unsigned long long t_recwait = 0, t_capb = 0, t_sysr = 0, t_f4 = 0, t_f1 = 0, t_gen = 0;)
+    CORE_PROF(unsigned long long t_begin = prof_now(); unsigned long long t_wait = 0, t_stepping = 0, t_mark = 0; int n_waits = 0, n_from_rec = 0, n_reclook = 0, n_fast4 = 0, n_capb = 0, n_sysr = 0, n_sysb = 0, n_f1 = 0, n_gen = 0, n_lazy = 0; unsigned long long t_lazy = 0, t_recwait = 0, t_capb = 0, t_sysr = 0, t_f4 = 0, t_f1 = 0, t_gen = 0;)
     // kSplit: the noise-floor passes come from the chain wave (CoreShare).  `own`: this wave advanced the noise floor itself since it
     // last took a value from there (single blocks, decays): the next value taken is only good if the chain wave agrees on the one
     // before it.  `solo`: the chain wave was given up on (a wait ran out): from then on this wave walks the chain itself.
@@ -1003,8 +1003,10 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
             } else {  // STEP: the 16 samples one by one
                 ++n_step;
                 if (!smp_ready) {
+                    CORE_PROF(const unsigned long long t_l0 = prof_now();)
                     smp = core_samples(a, x, g0, lane);
                     smp_ready = true;
+                    CORE_PROF(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_lazy += prof_now() - t_l0; ++n_lazy;)
                 }
                 if (valid) {  // full_ at the block end is already known exactly: only the capped_ chain is serial
                     // Everything that does not depend on c is done once per group, by all 64 lanes for their own blocks
@@ -1192,7 +1194,7 @@ __device__ __forceinline__ void core_walk(const TpArgs& a, LdsShare* sh, const i
         fe_group = rl(cur.fe, 63);
         CORE_PROF(++n_gen; t_gen += prof_now() - t_it0;)
     }
-    CORE_PROF(if (lane == 0 && r < 8) printf("core w1 row %d: groups by path: four at once %d in %llu us, whole group %d in %llu us, general %d in %llu us (stepping included)\n", r, n_fast4, t_f4 / 100, n_f1, t_f1 / 100, n_gen, t_gen / 100);)
+    CORE_PROF(if (lane == 0 && r < 8) printf("core w1 row %d: groups by path: four at once %d in %llu us, whole group %d in %llu us, general %d in %llu us (stepping included); raw samples asked for when a block had to be stepped: %d times, %llu us until they were there\n", r, n_fast4, t_f4 / 100, n_f1, t_f1 / 100, n_gen, t_gen / 100, n_lazy, t_lazy / 100);)
     CORE_PROF(if (lane == 0 && r < 8) printf("core w1 row %d: total %llu us  wait-w0 %llu us (%d waits)  stepping %llu us (record waits %llu us, %d looks)  run %d accepted-runs %d step %d (from records %d) fail %d rollback %d solo %d fast4 %d; cap-binding blocks %d in %llu us, systolic rounds %d (%d blocks) in %llu us\n", r,
                                            (prof_now() - t_begin) / 100, t_wait / 100, n_waits, t_stepping / 100, t_recwait / 100, n_reclook, n_run, n_single, n_step, n_from_rec, n_fail, n_rollback, (int)solo, n_fast4, n_capb, t_capb / 100, n_sysr, n_sysb, t_sysr / 100);)
     if (kSplit && lane == 0)
