@@ -387,8 +387,10 @@ __device__ __forceinline__ float nf_chain_guess64(float& nf, const float op, NfG
 //     a value no step can produce, so the group end needs no extra bit;
 //   * base of the next round (result of lane `last` - P of lane last + 1) is read with the same lane select as everything else: one
 //     scalar round trip per round (compare -> find first -> readlane), 34 ns for a round that ends the group, 60 ns for one that ends early
-//     and goes on (a lone step below the floor);
-//   * an exception the pattern did not have and a run below the floor leave the assembly block for the C++ around it.
+//     and goes on inside the assembly block (a lone step below the floor; a lone exception, which is NOT learnt: it is gone three
+//     blocks later, and learning and unlearning it cost two trips through the pattern code against one 60-ns round);
+//   * the second exception of a group (the start or the end of a train: its class learns the increment) and a run below the floor
+//     leave the assembly block for the C++ around it.
 // Soundness is the argument of nf_chain_guess64: lane kk's input is exact, and result_j - guess_j == pinc_j means result_j == guess_{j+1}
 // because guess_{j+1} - guess_j = P_{j+1} - P_j = pinc_j by construction (exact in 32 bits: increments < 2^22, 21 triples at most).
 struct NfGuessL {           // per lane (loop-carried scalars end up in vector registers anyway)
