@@ -522,6 +522,36 @@ def test_consecutive_calls_overlap_with_early_input(pkg, monkeypatch, calls):
         assert_same(wo[0], owo, f"audio ({streams} stream)")
 
 
+def test_timings_of_the_five_calls_before_the_last_stay_readable(pkg, monkeypatch):
+    """Six scratch / event sets cycle: a host that keeps calls in flight reads the kernel times of a call four or five calls later
+    (mi_demod_kernel_time_prev) without waiting for anything that is still queued; one further back the set has been taken again."""
+    import torch
+    monkeypatch.delenv("MI_AIRBAND_TP", raising=False)
+    centre, chans = pkg.config2_channels()
+    dev = pkg.device_cfg(centerfreq=centre)
+    k, ncalls = 8, 7
+    iq, _ = gen_iq(pkg, dev, centre, chans, k * ncalls, gate_div=3)
+    pad = (iq.size + 255) // 256 * 256
+    d_iq = torch.zeros(pad, dtype=torch.uint8, device="cuda")
+    d_iq[:iq.size] = torch.from_numpy(iq).cuda()
+    wo = [torch.empty((1, len(chans), k * WAVE_BATCH), dtype=torch.float32, device="cuda") for _ in range(3)]
+    ax = [torch.empty((1, len(chans), k), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    d = pkg.Demod(dev, chans, nstreams=1, max_batches=k)
+    d.set_option(pkg.OPT_EARLY_INPUT, 1)
+    for n in range(ncalls):
+        pos = 0 if n == 0 else (n * k * WAVE_BATCH + AGC_EXTRA) * d.hop_bytes
+        d.process_device(d_iq.data_ptr() + pos, pad - pos, k, wo[n % 3].data_ptr(), ax[n % 3].data_ptr(), hip_stream=side.cuda_stream)
+        assert d.last_path()[0] == 1
+    for age in range(6):
+        t = dict((name, ms) for name, ms, _ in d.kernel_times(age=age))
+        assert t.get("k_tp_core", 0.0) > 0.0, f"age {age}: {t}"
+    assert d.kernel_times(age=6) == []
+    torch.cuda.synchronize()
+    d.close()
+
+
 @pytest.mark.parametrize("split_cus", [128, 64, 0])
 def test_overlapped_serial_calls_on_disjoint_cus_keep_every_bit(pkg, monkeypatch, split_cus):
     """MI_OPT_SPLIT_CUS: overlapped calls on the serial kernel with k_demod alone on the last n CUs and stage 1 of the next call on the
