@@ -111,8 +111,11 @@ def run_workload(pkg, args, workload, steps, warmup, gather_mode, rank, world, l
     # (only where those streams are used -- plans of up to 64 rows on the time-parallel path: elsewhere a second user stream only takes a
     # hardware queue away from the library's own, BENCH_STREAM=null|side forces one)
     # (... and plans of 449 .. 512 rows on the serial kernel, whose stage 1 and k_demod take disjoint CUs: MI_OPT_SPLIT_CUS)
+    # (config3: the 16 plain AM rows of its mixed plan take the time-parallel path; with the wide passes off 32 CUs the serial kernel of the
+    #  other 16 rows finds free CUs as well: k_demod 1.73 -> 1.42 ms per call, 11.6 -> 14.0 GS/s)
     want_side = {"null": False, "side": True}.get(os.environ.get("BENCH_STREAM", ""),
-                                                  (nstreams * nch <= 64 and workload in ("config2", "am64")) or (workload == "am64" and 448 < nstreams * nch <= 512))
+                                                  (nstreams * nch <= 64 and workload in ("config2", "config3", "am64")) or
+                                                  (workload == "am64" and 448 < nstreams * nch <= 512))
     stream = torch.cuda.Stream() if want_side else torch.cuda.current_stream()
     torch.cuda.set_stream(stream)
 
