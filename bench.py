@@ -131,7 +131,10 @@ def run_workload(pkg, args, workload, steps, warmup, gather_mode, rank, world, l
     # The audio of a step is gathered to rank 0 while the next steps compute: three output buffers, and the host waits for
     # the gather of buffer b only when buffer b is about to be written again.
     gathering = gather_mode is not None and dist.is_initialized()
-    nbuf = 3  # consecutive steps write different audio buffers (the segment passes of step k+1 may run under the tail of step k)
+    # (consecutive steps write different audio buffers: the segment passes of step k+1 may run under the tail of step k.  Five of them:
+    #  with three the host waited for the gather of step k - 3 before it could submit step k, i.e. for the end of that step's tail, and the
+    #  pipeline was three calls deep -- the same bound the timing reads at age 3 put on it)
+    nbuf = int(os.environ.get("BENCH_NBUF", "5"))
     d_wos = [torch.empty((nstreams, nch, nsteps), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
     d_axcs = [torch.empty((nstreams, nch, nbat), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
     gath = shard.AudioGather((nstreams, nch, nsteps), nbat, torch.device("cuda", local_rank), dst=0) if gathering else None
