@@ -270,8 +270,16 @@ constexpr int kMixedMinBatches = 64;
 //   MI_AIRBAND_L64=0         no lane-resident stage 1 at N = 512 (the pruned / full exchange kernels instead)
 //   MI_AIRBAND_UNI_ROWS=n, MI_AIRBAND_TP_CHUNKS=n, MI_AIRBAND_TP_RATIO=x, MI_AIRBAND_TP_LPW=n
 void tuning_from_env(mi_demod* h) {
+    // (MI_AIRBAND_DEBUG=1: every tuning variable found in the environment is named on stderr when a handle is created -- a variable
+    //  exported for a test changes what a production handle does just as silently as it changes the test's)
+    static const bool debug = [] {
+        const char* e = std::getenv("MI_AIRBAND_DEBUG");
+        return e && *e && std::atoi(e) != 0;
+    }();
     auto get = [](const char* k) -> const char* {
         const char* e = std::getenv(k);
+        if (e && *e && debug)
+            std::fprintf(stderr, "mi_airband: %s=%s (from the environment)\n", k, e);
         return (e && *e) ? e : nullptr;
     };
     if (const char* e = get("MI_AIRBAND_TP"))

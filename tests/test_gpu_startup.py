@@ -94,3 +94,33 @@ def test_prepared_handle_first_call_equals_oracle_and_is_fast(pkg):
     assert_same(wo[0, :, :WAVE_BATCH], owo, "audio of the first call")
     assert np.array_equal(axc[0], oaxc)
     d.close()
+
+
+ENV_CHILD = r"""
+import sys
+sys.path.insert(0, %(tests)r)
+from conftest import load_package
+pkg = load_package()
+centre, chans = pkg.config2_channels()
+d = pkg.Demod(pkg.device_cfg(centerfreq=centre), chans, nstreams=1, max_batches=2, gpu=0)
+d.close()
+"""
+
+
+@pytest.mark.gpu
+def test_tuning_variables_in_the_environment_are_named_under_debug(tmp_path):
+    """MI_AIRBAND_DEBUG=1: a handle names every MI_AIRBAND_* tuning variable it found in the environment on stderr when it is created
+    (they are read per handle and change what it does without another word); without MI_AIRBAND_DEBUG it stays silent."""
+    code = ENV_CHILD % {"tests": os.path.join(ROOT, "tests")}
+    for debug in ("1", None):
+        env = dict(os.environ, MI_AIRBAND_TP="0", MI_AIRBAND_CORE_GUESS="2")
+        env.pop("MI_AIRBAND_DEBUG", None)
+        if debug:
+            env["MI_AIRBAND_DEBUG"] = debug
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        named = [l for l in r.stderr.splitlines() if l.startswith("mi_airband: MI_AIRBAND_")]
+        if debug:
+            assert any("MI_AIRBAND_TP=0" in l for l in named) and any("MI_AIRBAND_CORE_GUESS=2" in l for l in named), r.stderr[-2000:]
+        else:
+            assert not named, named
